@@ -1,0 +1,257 @@
+/*
+ * rehrseg_hip.h -- C-ABI of librehrseg_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the 3D-convolutional hot path of zhiyuns/REHRSeg.  The
+ * reference has no FFI of its own: its operator layer is torch.nn
+ * (Conv3d / ConvTranspose3d / InstanceNorm3d / LeakyReLU / F.interpolate, see
+ * the citations on every entry point).  These entry points are what a
+ * maintainer would bind with ctypes in place of those torch.nn calls
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (no allocation
+ *     happens behind the ABI; scratch comes from a caller-provided workspace);
+ *   - activations are fp32, channel-innermost ("NDHWC"): element (n,d,h,w,c) of
+ *     a tensor with voxel stride `ld` lives at ((n*D+d)*H+h)*W+w)*ld + c, so a
+ *     channel slice of a wider buffer is addressed by offsetting the pointer
+ *     and keeping `ld` (this is how skip concatenation costs nothing);
+ *   - `stream` is a hipStream_t passed as void*; launches are stream ordered,
+ *     re-entrant, and never synchronise;
+ *   - return value 0 = launched; <0 = rejected argument (REHR_E*), nothing was
+ *     launched.  No exceptions, no global state.
+ */
+#ifndef REHRSEG_HIP_H
+#define REHRSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REHR_OK 0
+#define REHR_EINVAL -1   /* malformed descriptor (sizes, alignment, null) */
+#define REHR_ENOSUP -2   /* valid but not supported by this build */
+#define REHR_EHIP -3     /* hip launch error */
+
+/* activation codes used by the fused epilogues */
+#define REHR_ACT_NONE 0
+#define REHR_ACT_RELU 1
+#define REHR_ACT_LRELU 2 /* slope given separately */
+
+/* Taps of one spatial axis, described arithmetically (no device tables):
+ * tap j (0 <= j < count) reads the source at  base + off0 + offs*j  and uses
+ * weight index  k0 + ks*j  along this axis.                                   */
+typedef struct {
+  int32_t count, off0, offs, k0, ks;
+} rehr_axis_taps;
+
+/* ------------------------------------------------------------------------- *
+ * Gather-GEMM: the one contraction behind Conv3d forward, Conv3d input
+ * gradient (one launch per stride phase), ConvTranspose3d forward (one launch
+ * per stride phase), ConvTranspose3d input gradient, and Conv2d (D = 1).
+ *
+ *   for every lattice point o=(od,oh,ow), sample n, output channel co:
+ *     y[n, o*os+ob, co] = act( bias[co] + sum_{taps j} sum_{ci}
+ *           x[n, o*s+b+off(j), ci] * wp[tap(j)][co][ci] )
+ *   (source positions outside [0,Di)x[0,Hi)x[0,Wi) read as zero)
+ *
+ * Replaces: torch.nn.Conv3d.forward as used at models/FLAVR/resnet_3D.py:19-33,
+ * 42-50, 196-200; models/FLAVR/FLAVR_arch.py:50,77,145,153-156;
+ * models/seg_model.py:197-199 and the PlainConvUNet blocks behind
+ * models/seg_model.py:174-191, plus the autograd input-gradient of each.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  /* source tensor(s): channels [0,c1) come from x1, [c1,Cin) from x2 (virtual
+   * concat, models/FLAVR/FLAVR_arch.py:14-21); x2 may be NULL when c1 == Cin. */
+  const float* x1;
+  const float* x2;
+  int32_t c1, ldx1, ldx2;
+  int32_t N, Di, Hi, Wi, Cin;      /* Cin % 32 == 0, c1 % 32 == 0 */
+  /* lattice and its map into the source */
+  int32_t Ld, Lh, Lw;
+  int32_t sd, sh, sw, bd, bh, bw;
+  rehr_axis_taps td, th, tw;
+  int32_t KH, KW;                  /* weight tap index = (kd*KH+kh)*KW+kw */
+  /* packed weights wp[tap][Npad][Cin] (ci innermost), Npad % 32 == 0 */
+  const float* wp;
+  int32_t Npad;
+  /* destination tensor and the lattice's map into it */
+  float* y;
+  int32_t Dy, Hy, Wy, Cout, ldy;
+  int32_t osd, osh, osw, obd, obh, obw;
+  /* fused epilogue */
+  const float* bias;               /* NULL or [Cout] */
+  int32_t act;
+  float slope;
+  /* optional per-(n,co) statistics of the stored value, accumulated with
+   * double atomics into stats[n][co][2] = {sum, sum of squares}; 0 = off,
+   * 1 = sum only (SEGating pool), 2 = sum and squares (InstanceNorm3d).       */
+  double* stats;
+  int32_t stats_mode;
+  /* lattice tile: a td x th x tw brick with td*th*tw == 128, or tile_d == 0
+   * for runs of 128 consecutive flattened lattice points (odd extents)         */
+  int32_t tile_d, tile_h, tile_w;
+} rehr_gather_gemm_desc;
+
+int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Weight gradient (Conv3d.weight.grad / ConvTranspose3d.weight.grad):
+ *
+ *   dst[a*dst_sa + c*dst_sc + tap*dst_st] = sum_{n, lattice o}
+ *         l[n, o, a] * g[n, o*s+b+off(tap), c]
+ *
+ * l = the tensor living ON the lattice (dY for Conv3d, the input for
+ * ConvTranspose3d), g = the gathered tensor (X for Conv3d, dY for
+ * ConvTranspose3d).  Deterministic: partial sums go to `workspace` slabs
+ * and are reduced in a fixed order.
+ * Replaces autograd's conv weight gradient for the call sites listed above.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  const float* l;
+  int32_t ldl, Ca;                 /* Ca % 32 == 0 */
+  const float* g;
+  int32_t ldg, Cg;                 /* Cg % 32 == 0 */
+  int32_t N, Ld, Lh, Lw;           /* lattice (= spatial dims of l) */
+  int32_t Dg, Hg, Wg;              /* spatial dims of g */
+  int32_t sd, sh, sw, bd, bh, bw;
+  rehr_axis_taps td, th, tw;
+  int32_t KH, KW;
+  float* dst;
+  int64_t dst_sa, dst_sc, dst_st;
+  int32_t accumulate;              /* 0: dst = sum, 1: dst += sum */
+  float* workspace;                /* >= rehr_wgrad_workspace_bytes() */
+  int64_t workspace_bytes;
+  float* dbias;                    /* NULL or [Ca]: dbias[a] (+)= sum l[...,a] */
+} rehr_wgrad_desc;
+
+int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* d);
+int rehr_wgrad_f32(const rehr_wgrad_desc* d, void* stream);
+
+/* out[t][a][b] = in[a][b][t] (transpose_ab = 0) or in[b][a][t] (1); rows
+ * a >= A are written as zero up to Apad.  Turns the (Cout,Cin,kD,kH,kW)
+ * parameter layout of torch.nn.Conv3d / the (Cin,Cout,...) layout of
+ * ConvTranspose3d into wp[tap][Npad][Cin].                                   */
+int rehr_pack_weights_f32(const float* in, float* out, int32_t A, int32_t Apad,
+                          int32_t B, int32_t T, int32_t transpose_ab,
+                          void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Direct convolution for Cin in {1,2} -> Cout in {16,32,64} (HBM bound, no
+ * MFMA): the stem Conv3d (3,7,7)/(1,2,2) of models/FLAVR/resnet_3D.py:47-48
+ * and the first nnU-Net conv.  Weights stay in the torch parameter layout
+ * (Cout,Cin,kD,kH,kW); x/y are NDHWC.  The input of these layers is the
+ * network input, so no input gradient exists.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  const float* x;
+  int32_t ldx, N, Di, Hi, Wi, Cin;
+  const float* w;                  /* (Cout,Cin,KD,KH,KW) */
+  const float* bias;               /* NULL or [Cout] */
+  float* y;                        /* forward: output; wgrad: dY (read) */
+  int32_t ldy, Do, Ho, Wo, Cout;
+  int32_t KD, KH, KW, sd, sh, sw, pd, ph, pw;
+  int32_t act;
+  float slope;
+  double* stats;
+  int32_t stats_mode;
+} rehr_direct_conv_desc;
+
+int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* d, void* stream);
+int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc* d);
+/* dw (Cout,Cin,KD,KH,KW) = sum_{n,o} dY[n,o,co] * x[n,o*s-p+k,ci]; dbias optional */
+int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* d, float* dw,
+                                  float* dbias, float* workspace,
+                                  int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * SEGating (models/FLAVR/resnet_3D.py:100-116) and its fused neighbours.
+ *   gate[n][c] = sigmoid( b[c] + sum_k W[c][k] * stats[n][k][0] / S )
+ *   y = act( x * gate[n][c] + res )      (res optional: BasicBlock :144-149;
+ *                                         act lrelu(0.2): FLAVR_arch.py:188-200)
+ * ------------------------------------------------------------------------- */
+int rehr_se_gate_fwd_f32(const double* stats, const float* w, const float* b,
+                         float* gate, float* mean, int32_t N, int32_t C,
+                         int64_t S, void* stream);
+int rehr_scale_res_act_fwd_f32(const float* x, int32_t ldx, const float* gate,
+                               const float* res, int32_t ldr, float* y,
+                               int32_t ldy, int32_t N, int64_t S, int32_t C,
+                               int32_t act, float slope, void* stream);
+/* dz = dy * act'(y); dres = dz (optional); dx = dz * gate;
+ * dgate_acc[n][c] += sum_s dz * x   (double)                                 */
+int rehr_scale_res_act_bwd_f32(const float* dy, int32_t lddy, const float* y,
+                               int32_t ldy, const float* x, int32_t ldx,
+                               const float* gate, float* dx, int32_t lddx,
+                               float* dres, int32_t lddr, double* dgate_acc,
+                               int32_t N, int64_t S, int32_t C, int32_t act,
+                               float slope, void* stream);
+/* From dgate_acc: ds = dgate*g*(1-g); dW += ds (x) mean; db += ds;
+ * kconst[n][c] = (W^T ds)[c] / S.                                             */
+int rehr_se_gate_bwd_f32(const double* dgate_acc, const float* gate,
+                         const float* mean, const float* w, float* dw,
+                         float* db, float* kconst, int32_t N, int32_t C,
+                         int64_t S, void* stream);
+/* x[n,s,c] += k[n][c] in place */
+int rehr_add_channel_const_f32(float* x, int32_t ldx, const float* k, int32_t N,
+                               int64_t S, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * InstanceNorm3d(affine, eps) + LeakyReLU applied to a conv output whose
+ * {sum, sum of squares} were accumulated by the conv epilogue
+ * (nnU-Net ConvDropoutNormReLU: dynamic_network_architectures==0.3.1, call
+ * sites models/seg_model.py:174-191).
+ *   mean = s1/S; var = s2/S - mean^2 (biased); rstd = 1/sqrt(var+eps)
+ *   y = lrelu( (x-mean)*rstd*gamma + beta )
+ * ------------------------------------------------------------------------- */
+int rehr_instnorm_act_fwd_f32(const float* x, int32_t ldx, const double* stats,
+                              const float* gamma, const float* beta, float* y,
+                              int32_t ldy, float* mean_rstd /* [N][C][2] */,
+                              int32_t N, int64_t S, int32_t C, float eps,
+                              int32_t act, float slope, void* stream);
+/* dz = dy*act'(xhat*gamma+beta); dgamma = sum dz*xhat; dbeta = sum dz;
+ * dx = rstd*gamma*(dz - mean_s(dz) - xhat*mean_s(dz*xhat)).  `red` is a
+ * caller-zeroed [N][C][2] double scratch.                                     */
+int rehr_instnorm_act_bwd_f32(const float* dy, int32_t lddy, const float* x,
+                              int32_t ldx, const float* mean_rstd,
+                              const float* gamma, const float* beta, float* dx,
+                              int32_t lddx, float* dgamma, float* dbeta,
+                              double* red, int32_t N, int64_t S, int32_t C,
+                              int32_t act, float slope, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Depth-only linear upsample, align_corners=True
+ * (F.interpolate(scale_factor=(upscale,1,1), mode='trilinear'),
+ * models/seg_model.py:204).  Do = floor(Di*upscale).
+ * ------------------------------------------------------------------------- */
+int rehr_upsample_depth_fwd_f32(const float* x, float* y, int32_t N, int32_t Di,
+                                int32_t Do, int64_t HW, int32_t C, void* stream);
+int rehr_upsample_depth_bwd_f32(const float* dy, float* dx, int32_t N,
+                                int32_t Di, int32_t Do, int64_t HW, int32_t C,
+                                void* stream);
+
+/* Elementwise helpers used by the blocks above. */
+int rehr_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act,
+                     float slope, void* stream);
+int rehr_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n,
+                     int32_t act, float slope, void* stream);
+/* out[c] (+)= sum over rows of x[row*ld + c], rows = N*S (bias gradient).     */
+int rehr_channel_sum_f32(const float* x, int32_t ldx, int64_t rows, int32_t C,
+                         float* out, int32_t accumulate, double* scratch,
+                         void* stream);
+/* strided channel-slice copy: y[row*ldy + c] = x[row*ldx + c], c < C          */
+int rehr_copy_channels_f32(const float* x, int32_t ldx, float* y, int32_t ldy,
+                           int64_t rows, int32_t C, void* stream);
+/* NCDHW <-> NDHWC for API-edge tensors                                        */
+int rehr_nchw_to_nhwc_f32(const float* x, float* y, int32_t N, int32_t C,
+                          int64_t S, void* stream);
+int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_t C,
+                          int64_t S, void* stream);
+
+/* ABI version, bumped on any signature change. */
+int rehr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REHRSEG_HIP_H */

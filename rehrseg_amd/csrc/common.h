@@ -1,0 +1,46 @@
+// Shared device/host helpers for the gfx950 kernels of librehrseg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rehrseg_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define REHR_LAUNCH_CHECK()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return REHR_EHIP;                  \
+  } while (0)
+
+// Bijective XCD-aware remap of a 1-D grid: blocks that the dispatcher places on
+// the same XCD (b % 8 equal) become consecutive logical ids, so neighbouring
+// tiles (shared halo / shared weight panel) hit the same 4 MiB L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  if (act == REHR_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == REHR_ACT_LRELU) return v > 0.f ? v : v * slope;
+  return v;
+}
+// derivative factor given the OUTPUT of the activation (slope > 0 keeps sign)
+__device__ __forceinline__ float act_grad(float y, int act, float slope) {
+  if (act == REHR_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == REHR_ACT_LRELU) return y > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,264 @@
+// Direct (non-MFMA) convolutions for thin channel counts.  These layers have
+// almost no arithmetic per byte (Cin in {1,2} or Cout <= 4), so they are written
+// for the HBM roofline: NDHWC, 16-byte stores, weights staged once per block in
+// LDS and read with wave-uniform (broadcast) addresses.
+#include "common.h"
+
+namespace {
+
+constexpr int DC_THREADS = 256;
+
+// ------------------------------------------------------------------ small Cin, forward
+// wave -> 16-channel group (and voxel sub-tile when Cout < 64); lane -> voxel.
+__global__ __launch_bounds__(DC_THREADS) void small_cin_fwd_kernel(const rehr_direct_conv_desc d,
+                                                                   int groups, int tiles_per_img) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cin*T][Cout]
+  const int T = d.KD * d.KH * d.KW;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < d.Cout * d.Cin * T; i += DC_THREADS) {
+    const int co = i / (d.Cin * T), rem = i - co * (d.Cin * T);
+    wl[rem * d.Cout + co] = d.w[i];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = wave % groups, vt = wave / groups;
+  const int vpb = 64 * (4 / groups);
+  const int n = blockIdx.y;
+  const int64_t ovox = (int64_t)d.Do * d.Ho * d.Wo;
+  const int how = d.Ho * d.Wo;
+  const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
+  float* yn = d.y + (int64_t)n * ovox * d.ldy;
+
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = d.bias ? d.bias[g * 16 + j] : 0.f;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+  for (int tile = blockIdx.x; tile < tiles_per_img; tile += gridDim.x) {
+    const int64_t v = (int64_t)tile * vpb + vt * 64 + lane;
+    const bool valid = v < ovox;
+    int od = 0, oh = 0, ow = 0;
+    if (valid) {
+      od = (int)(v / how);
+      const int rem = (int)(v - (int64_t)od * how);
+      oh = rem / d.Wo;
+      ow = rem - oh * d.Wo;
+    }
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bv[j];
+    const int id0 = od * d.sd - d.pd, ih0 = oh * d.sh - d.ph, iw0 = ow * d.sw - d.pw;
+    for (int kd = 0; kd < d.KD; ++kd) {
+      const int id = id0 + kd;
+      for (int kh = 0; kh < d.KH; ++kh) {
+        const int ih = ih0 + kh;
+        const bool rowok = valid && (unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi;
+        const float* xr = xn + ((int64_t)id * d.Hi + ih) * d.Wi * d.ldx;
+        for (int kw = 0; kw < d.KW; ++kw) {
+          const int iw = iw0 + kw;
+          const bool ok = rowok && (unsigned)iw < (unsigned)d.Wi;
+          const int t = (kd * d.KH + kh) * d.KW + kw;
+          for (int ci = 0; ci < d.Cin; ++ci) {
+            const float xv = ok ? xr[(int64_t)iw * d.ldx + ci] : 0.f;
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (ci * T + t) * d.Cout + g * 16);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+              const f32x4 wv = wp[k4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[k4 * 4 + e] += xv * wv[e];
+            }
+          }
+        }
+      }
+    }
+    if (valid) {
+      float* yo = yn + v * d.ldy + g * 16;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r = apply_act(acc[k4 * 4 + e], d.act, d.slope);
+          o[e] = r;
+          s1[k4 * 4 + e] += r;
+          s2[k4 * 4 + e] += r * r;
+        }
+        *reinterpret_cast<f32x4*>(yo + k4 * 4) = o;
+      }
+    }
+  }
+  if (d.stats_mode != 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float a = wave_sum(s1[j]);
+      const float b = wave_sum(s2[j]);
+      if (lane == 0) {
+        double* st = d.stats + ((int64_t)n * d.Cout + g * 16 + j) * 2;
+        atomicAdd(st, (double)a);
+        if (d.stats_mode == 2) atomicAdd(st + 1, (double)b);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ small Cin, weight gradient
+// lanes <-> output channels (Cout <= 64), waves split the taps, blocks split the
+// voxels; the x sample of a (voxel, tap) is wave-uniform.  Partials go to
+// slab[block][Cin*T][Cout] (+ bias row) and are reduced deterministically.
+template <int TPW>  // taps per wave, compile-time bound for the register accumulators
+__global__ __launch_bounds__(DC_THREADS) void small_cin_wgrad_kernel(const rehr_direct_conv_desc d,
+                                                                     float* __restrict__ slab,
+                                                                     int64_t vox_per_block) {
+  const int T = d.KD * d.KH * d.KW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tpw = (T + 3) / 4;
+  const int t_begin = wave * tpw;
+  const int64_t ovox = (int64_t)d.Do * d.Ho * d.Wo;
+  const int64_t total = (int64_t)d.N * ovox;
+  const int64_t v_begin = (int64_t)blockIdx.x * vox_per_block;
+  int64_t v_end = v_begin + vox_per_block;
+  if (v_end > total) v_end = total;
+  const int how = d.Ho * d.Wo;
+  const bool lane_ok = lane < d.Cout;
+
+  float acc[2][TPW];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[ci][j] = 0.f;
+  float bsum = 0.f;
+
+  for (int64_t v = v_begin; v < v_end; ++v) {
+    const int n = (int)(v / ovox);
+    const int64_t r0 = v - (int64_t)n * ovox;
+    const int od = (int)(r0 / how);
+    const int rem = (int)(r0 - (int64_t)od * how);
+    const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+    const float dyv = lane_ok ? d.y[v * d.ldy + lane] : 0.f;
+    bsum += dyv;
+    const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
+    const int id0 = od * d.sd - d.pd, ih0 = oh * d.sh - d.ph, iw0 = ow * d.sw - d.pw;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int t = t_begin + j;
+      if (j < tpw && t < T) {
+        const int kw = t % d.KW, kh = (t / d.KW) % d.KH, kd = t / (d.KW * d.KH);
+        const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
+        if ((unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi && (unsigned)iw < (unsigned)d.Wi) {
+          const float* xp = xn + (((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx;
+          acc[0][j] += dyv * xp[0];
+          if (d.Cin > 1) acc[1][j] += dyv * xp[1];
+        }
+      }
+    }
+  }
+  float* sb = slab + (int64_t)blockIdx.x * ((int64_t)d.Cin * T + 1) * 64;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int t = t_begin + j;
+    if (j < tpw && t < T) {
+      sb[(int64_t)(0 * T + t) * 64 + lane] = acc[0][j];
+      if (d.Cin > 1) sb[(int64_t)(1 * T + t) * 64 + lane] = acc[1][j];
+    }
+  }
+  if (wave == 0) sb[(int64_t)d.Cin * T * 64 + lane] = bsum;
+}
+
+__global__ void small_cin_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, int Cin,
+                                              int T, int Cout, float* __restrict__ dw,
+                                              float* __restrict__ dbias) {
+  const int rows = Cin * T + 1;
+  const int total = rows * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i & 63, r = i >> 6;
+    if (co >= Cout) continue;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += slab[((int64_t)b * rows + r) * 64 + co];
+    if (r == Cin * T) {
+      if (dbias) dbias[co] = s;
+    } else {
+      const int ci = r / T, t = r - ci * T;
+      dw[((int64_t)co * Cin + ci) * T + t] = s;
+    }
+  }
+}
+
+bool small_cin_ok(const rehr_direct_conv_desc& d) {
+  if (!d.x || !d.w || !d.y) return false;
+  if (d.Cin < 1 || d.Cin > 2) return false;
+  if (d.Cout != 16 && d.Cout != 32 && d.Cout != 64) return false;
+  if (d.ldy % 4 || (((uintptr_t)d.y) & 15)) return false;
+  if (d.N < 1 || d.N > 65535) return false;
+  if (d.KD < 1 || d.KH < 1 || d.KW < 1 || d.sd < 1 || d.sh < 1 || d.sw < 1) return false;
+  // output extent must follow from the input extent
+  if ((d.Di + 2 * d.pd - d.KD) / d.sd + 1 != d.Do) return false;
+  if ((d.Hi + 2 * d.ph - d.KH) / d.sh + 1 != d.Ho) return false;
+  if ((d.Wi + 2 * d.pw - d.KW) / d.sw + 1 != d.Wo) return false;
+  return true;
+}
+
+int wgrad_blocks(const rehr_direct_conv_desc& d, int64_t* vpb) {
+  const int64_t total = (int64_t)d.N * d.Do * d.Ho * d.Wo;
+  int64_t blocks = 1024;
+  int64_t per = (total + blocks - 1) / blocks;
+  if (per < 64) per = 64;
+  blocks = (total + per - 1) / per;
+  *vpb = per;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* dp, void* stream) {
+  if (!dp || !small_cin_ok(*dp)) return REHR_EINVAL;
+  const rehr_direct_conv_desc& d = *dp;
+  if (d.stats_mode != 0 && !d.stats) return REHR_EINVAL;
+  const int T = d.KD * d.KH * d.KW;
+  const size_t smem = (size_t)d.Cin * T * d.Cout * sizeof(float);
+  if (smem > 64 * 1024) return REHR_ENOSUP;
+  const int groups = d.Cout / 16;
+  const int vpb = 64 * (4 / groups);
+  const int64_t ovox = (int64_t)d.Do * d.Ho * d.Wo;
+  const int tiles = (int)((ovox + vpb - 1) / vpb);
+  int bx = tiles;
+  const int cap = 4096 / d.N > 0 ? 4096 / d.N : 1;
+  if (bx > cap) bx = cap;
+  hipLaunchKernelGGL(small_cin_fwd_kernel, dim3(bx, d.N), dim3(DC_THREADS), smem, (hipStream_t)stream, d,
+                     groups, tiles);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* dp, float* dw, float* dbias,
+                                             float* workspace, int64_t workspace_bytes, void* stream) {
+  if (!dp || !small_cin_ok(*dp) || !dw || !workspace) return REHR_EINVAL;
+  const rehr_direct_conv_desc& d = *dp;
+  const int T = d.KD * d.KH * d.KW;
+  int64_t vpb;
+  const int blocks = wgrad_blocks(d, &vpb);
+  const int64_t need = (int64_t)blocks * ((int64_t)d.Cin * T + 1) * 64 * sizeof(float);
+  if (workspace_bytes < need) return REHR_EINVAL;
+  const int tpw = (T + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (tpw <= 8)
+    hipLaunchKernelGGL(small_cin_wgrad_kernel<8>, dim3(blocks), dim3(DC_THREADS), 0, st, d, workspace, vpb);
+  else if (tpw <= 40)
+    hipLaunchKernelGGL(small_cin_wgrad_kernel<40>, dim3(blocks), dim3(DC_THREADS), 0, st, d, workspace, vpb);
+  else
+    return REHR_ENOSUP;
+  hipLaunchKernelGGL(small_cin_wgrad_reduce_kernel, dim3(((d.Cin * T + 1) * 64 + 255) / 256), dim3(256), 0,
+                     st, workspace, blocks, d.Cin, T, d.Cout, dw, dbias);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc* dp) {
+  if (!dp) return REHR_EINVAL;
+  int64_t vpb;
+  const int blocks = wgrad_blocks(*dp, &vpb);
+  const int T = dp->KD * dp->KH * dp->KW;
+  return (int64_t)blocks * ((int64_t)dp->Cin * T + 1) * 64 * sizeof(float);
+}

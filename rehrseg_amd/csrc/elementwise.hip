@@ -1,0 +1,668 @@
+// HBM-bound kernels of the hot path: SEGating (gate, scale+residual+activation
+// and their gradients), InstanceNorm3d+LeakyReLU (apply and gradient), depth-only
+// linear upsample, bias-gradient column sums, weight packing and layout edges.
+//
+// All tensors are NDHWC fp32; every streaming access is a 16-byte load/store per
+// lane with the channel index innermost, so a wave touches 1 KiB contiguous.
+// Per-(sample, channel) reductions keep the channel quad fixed per thread, reduce
+// over a block's rows in registers + LDS, and finish with one double atomic per
+// channel per block.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAX_BLOCKS = 2048;  // 256 CUs x 8
+
+inline int ew_blocks(int64_t work_items) {
+  int64_t b = (work_items + EW_THREADS - 1) / EW_THREADS;
+  if (b > EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- pack weights
+__global__ void pack_weights_kernel(const float* __restrict__ in, float* __restrict__ out, int A,
+                                    int Apad, int B, int T, int transpose_ab) {
+  const int64_t total = (int64_t)T * Apad * B;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % B);
+    const int64_t r = i / B;
+    const int a = (int)(r % Apad);
+    const int t = (int)(r / Apad);
+    float v = 0.f;
+    if (a < A) v = transpose_ab ? in[((int64_t)b * A + a) * T + t] : in[((int64_t)a * B + b) * T + t];
+    out[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------- SE gate
+// one wave per (n, c): gate = sigmoid(b[c] + W[c,:] . mean[n,:])
+__global__ void se_gate_fwd_kernel(const double* __restrict__ stats, const float* __restrict__ w,
+                                   const float* __restrict__ b, float* __restrict__ gate,
+                                   float* __restrict__ mean, int N, int C, double invS) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + wave;
+  const int n = blockIdx.y;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int k = lane; k < C; k += 64) {
+    const float m = (float)(stats[((int64_t)n * C + k) * 2] * invS);
+    if (c == 0 || (blockIdx.x == 0 && wave == 0)) mean[(int64_t)n * C + k] = m;
+    acc += w[(int64_t)c * C + k] * m;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) gate[(int64_t)n * C + c] = 1.f / (1.f + __expf(-(acc + b[c])));
+}
+
+// dW[c][k] = sum_n ds[n][c] * mean[n][k]; db[c] = sum_n ds[n][c]; ds = dg*g*(1-g)
+__global__ void se_gate_bwd_w_kernel(const double* __restrict__ dgate, const float* __restrict__ gate,
+                                     const float* __restrict__ mean, float* __restrict__ dw,
+                                     float* __restrict__ db, int N, int C) {
+  const int64_t total = (int64_t)C * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % C), c = (int)(i / C);
+    float s = 0.f, sb = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float g = gate[(int64_t)n * C + c];
+      const float ds = (float)dgate[(int64_t)n * C + c] * g * (1.f - g);
+      s += ds * mean[(int64_t)n * C + k];
+      sb += ds;
+    }
+    dw[i] = s;
+    if (k == 0) db[c] = sb;
+  }
+}
+// kconst[n][k] = (sum_c W[c][k] * ds[n][c]) / S
+__global__ void se_gate_bwd_k_kernel(const double* __restrict__ dgate, const float* __restrict__ gate,
+                                     const float* __restrict__ w, float* __restrict__ kconst, int N,
+                                     int C, float invS) {
+  const int64_t total = (int64_t)N * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % C), n = (int)(i / C);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float g = gate[(int64_t)n * C + c];
+      const float ds = (float)dgate[(int64_t)n * C + c] * g * (1.f - g);
+      s += w[(int64_t)c * C + k] * ds;
+    }
+    kconst[i] = s * invS;
+  }
+}
+
+// ---------------------------------------------------------------- y = act(x*gate + res)
+__global__ void scale_res_act_fwd_kernel(const float* __restrict__ x, int ldx,
+                                         const float* __restrict__ gate,
+                                         const float* __restrict__ res, int ldr,
+                                         float* __restrict__ y, int ldy, int64_t rows, int64_t S,
+                                         int C, int act, float slope) {
+  const int c4n = C >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const int64_t row = i / c4n;
+    const int n = (int)(row / S);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (int64_t)n * C + c);
+    f32x4 v = xv * gv;
+    if (res != nullptr) v += *reinterpret_cast<const f32x4*>(res + row * ldr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+    *reinterpret_cast<f32x4*>(y + row * ldy + c) = v;
+  }
+}
+
+// Column-reduction skeleton: a block owns `rows_per_block` consecutive rows of
+// ONE sample; thread t owns channel quad (t % c4n) and walks rows t / c4n,
+// + rpp, ...  NQ quantities x 4 channels are reduced over the block in LDS and
+// finished with one double atomic per (quantity, channel).
+template <int NQ, typename F>
+__device__ __forceinline__ void column_reduce(int64_t row_begin, int64_t row_end, int C, double* out,
+                                              int out_stride, F body) {
+  __shared__ float red[EW_THREADS * NQ * 4];
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int rpp = EW_THREADS / c4n;  // rows per pass (c4n <= 256)
+  const int cq = tid % c4n, rl = tid / c4n;
+  float acc[NQ][4];
+#pragma unroll
+  for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[qn][e] = 0.f;
+  if (rl < rpp) {
+    for (int64_t r = row_begin + rl; r < row_end; r += rpp) body(r, cq * 4, acc);
+  }
+#pragma unroll
+  for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(qn * 4 + e) * EW_THREADS + tid] = (rl < rpp) ? acc[qn][e] : 0.f;
+  __syncthreads();
+  // thread (qn, e, cq) sums the rl copies
+  for (int o = tid; o < NQ * 4 * c4n; o += EW_THREADS) {
+    const int cqq = o % c4n, qe = o / c4n;
+    double s = 0.0;
+    for (int k = 0; k < rpp; ++k) s += (double)red[qe * EW_THREADS + k * c4n + cqq];
+    const int qn = qe >> 2, e = qe & 3;
+    atomicAdd(out + (int64_t)(cqq * 4 + e) * out_stride + qn, s);
+  }
+}
+
+// dz = dy*act'(y); dres = dz; dx = dz*gate; dgate_acc[n][c] += sum dz*x
+__global__ void scale_res_act_bwd_kernel(const float* __restrict__ dy, int lddy,
+                                         const float* __restrict__ y, int ldy,
+                                         const float* __restrict__ x, int ldx,
+                                         const float* __restrict__ gate, float* __restrict__ dx,
+                                         int lddx, float* __restrict__ dres, int lddr,
+                                         double* __restrict__ dgate_acc, int64_t S, int C,
+                                         int64_t rows_per_block, int act, float slope) {
+  const int n = blockIdx.y;
+  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t s_end = s_begin + rows_per_block;
+  if (s_end > S) s_end = S;
+  const int64_t base = (int64_t)n * S;
+  column_reduce<1>(base + s_begin, base + s_end, C, dgate_acc + (int64_t)n * C, 1,
+                   [&](int64_t row, int c, float(&acc)[1][4]) {
+                     const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
+                     const f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ldy + c);
+                     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+                     const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (int64_t)n * C + c);
+                     f32x4 dz;
+#pragma unroll
+                     for (int e = 0; e < 4; ++e) dz[e] = dyv[e] * act_grad(yv[e], act, slope);
+                     if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + row * lddr + c) = dz;
+                     *reinterpret_cast<f32x4*>(dx + row * lddx + c) = dz * gv;
+#pragma unroll
+                     for (int e = 0; e < 4; ++e) acc[0][e] += dz[e] * xv[e];
+                   });
+}
+
+__global__ void add_channel_const_kernel(float* __restrict__ x, int ldx, const float* __restrict__ k,
+                                         int64_t rows, int64_t S, int C) {
+  const int c4n = C >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const int64_t row = i / c4n;
+    const int n = (int)(row / S);
+    f32x4* p = reinterpret_cast<f32x4*>(x + row * ldx + c);
+    *p = *p + *reinterpret_cast<const f32x4*>(k + (int64_t)n * C + c);
+  }
+}
+
+// ---------------------------------------------------------------- InstanceNorm + act
+__global__ void instnorm_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mr,
+                                         int64_t NC, double invS, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NC;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double m = stats[i * 2] * invS;
+    double var = stats[i * 2 + 1] * invS - m * m;
+    if (var < 0.0) var = 0.0;
+    mr[i * 2] = (float)m;
+    mr[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+__global__ void instnorm_act_fwd_kernel(const float* __restrict__ x, int ldx,
+                                        const float* __restrict__ mr,
+                                        const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* __restrict__ y,
+                                        int ldy, int64_t rows, int64_t S, int C, int act,
+                                        float slope) {
+  const int c4n = C >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const int64_t row = i / c4n;
+    const int n = (int)(row / S);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+    const float* m = mr + ((int64_t)n * C + c) * 2;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xv[e] - m[2 * e]) * m[2 * e + 1];
+      v[e] = apply_act(xh * gamma[c + e] + beta[c + e], act, slope);
+    }
+    *reinterpret_cast<f32x4*>(y + row * ldy + c) = v;
+  }
+}
+
+// pass 1: red[n][c] = { sum dz, sum dz*xhat },  dz = dy * act'(xhat*gamma+beta)
+__global__ void instnorm_bwd_reduce_kernel(const float* __restrict__ dy, int lddy,
+                                           const float* __restrict__ x, int ldx,
+                                           const float* __restrict__ mr,
+                                           const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, double* __restrict__ red,
+                                           int64_t S, int C, int64_t rows_per_block, int act,
+                                           float slope) {
+  const int n = blockIdx.y;
+  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t s_end = s_begin + rows_per_block;
+  if (s_end > S) s_end = S;
+  const int64_t base = (int64_t)n * S;
+  column_reduce<2>(base + s_begin, base + s_end, C, red + (int64_t)n * C * 2, 2,
+                   [&](int64_t row, int c, float(&acc)[2][4]) {
+                     const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
+                     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+                     const float* m = mr + ((int64_t)n * C + c) * 2;
+#pragma unroll
+                     for (int e = 0; e < 4; ++e) {
+                       const float xh = (xv[e] - m[2 * e]) * m[2 * e + 1];
+                       const float z = xh * gamma[c + e] + beta[c + e];
+                       const float dz = dyv[e] * act_grad(z, act, slope);
+                       acc[0][e] += dz;
+                       acc[1][e] += dz * xh;
+                     }
+                   });
+}
+// dgamma[c] = sum_n red[n][c][1]; dbeta[c] = sum_n red[n][c][0]
+__global__ void instnorm_bwd_params_kernel(const double* __restrict__ red, float* __restrict__ dgamma,
+                                           float* __restrict__ dbeta, int N, int C) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) {
+      b += red[((int64_t)n * C + c) * 2];
+      a += red[((int64_t)n * C + c) * 2 + 1];
+    }
+    dgamma[c] = (float)a;
+    dbeta[c] = (float)b;
+  }
+}
+// pass 2: dx = rstd*gamma*(dz - m1 - xhat*m2)
+__global__ void instnorm_bwd_apply_kernel(const float* __restrict__ dy, int lddy,
+                                          const float* __restrict__ x, int ldx,
+                                          const float* __restrict__ mr,
+                                          const float* __restrict__ gamma,
+                                          const float* __restrict__ beta,
+                                          const double* __restrict__ red, float* __restrict__ dx,
+                                          int lddx, int64_t rows, int64_t S, int C, int act,
+                                          float slope) {
+  const int c4n = C >> 2;
+  const int64_t total = rows * c4n;
+  const double invS = 1.0 / (double)S;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const int64_t row = i / c4n;
+    const int n = (int)(row / S);
+    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+    const float* m = mr + ((int64_t)n * C + c) * 2;
+    const double* rd = red + ((int64_t)n * C + c) * 2;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xv[e] - m[2 * e]) * m[2 * e + 1];
+      const float z = xh * gamma[c + e] + beta[c + e];
+      const float dz = dyv[e] * act_grad(z, act, slope);
+      const float m1 = (float)(rd[2 * e] * invS), m2 = (float)(rd[2 * e + 1] * invS);
+      o[e] = m[2 * e + 1] * gamma[c + e] * (dz - m1 - xh * m2);
+    }
+    *reinterpret_cast<f32x4*>(dx + row * lddx + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------- depth upsample
+__device__ __forceinline__ void depth_src(int od, int Di, int Do, int& i0, int& i1, float& w1) {
+  // align_corners=True: src = od * (Di-1)/(Do-1)
+  const float scale = (Do > 1) ? (float)(Di - 1) / (float)(Do - 1) : 0.f;
+  const float src = scale * (float)od;
+  i0 = (int)src;
+  if (i0 > Di - 1) i0 = Di - 1;
+  i1 = (i0 < Di - 1) ? i0 + 1 : i0;
+  w1 = src - (float)i0;
+}
+__global__ void upsample_depth_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                          int Di, int Do, int64_t HW, int C) {
+  const int64_t plane = HW * C / 4;  // float4 per depth slice
+  const int64_t total = (int64_t)N * Do * plane;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % plane;
+    const int64_t r = i / plane;
+    const int od = (int)(r % Do), n = (int)(r / Do);
+    int i0, i1;
+    float w1;
+    depth_src(od, Di, Do, i0, i1, w1);
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[((int64_t)n * Di + i0) * plane + p];
+    const f32x4 b = reinterpret_cast<const f32x4*>(x)[((int64_t)n * Di + i1) * plane + p];
+    reinterpret_cast<f32x4*>(y)[i] = a * (1.f - w1) + b * w1;
+  }
+}
+__global__ void upsample_depth_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                          int Di, int Do, int64_t HW, int C) {
+  const int64_t plane = HW * C / 4;
+  const int64_t total = (int64_t)N * Di * plane;
+  // outputs that can touch input slice id lie in [lo, hi]
+  const float inv = (Di > 1) ? (float)(Do - 1) / (float)(Di - 1) : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % plane;
+    const int64_t r = i / plane;
+    const int id = (int)(r % Di), n = (int)(r / Di);
+    int lo = (int)floorf((float)(id - 1) * inv) - 1, hi = (int)ceilf((float)(id + 1) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > Do - 1) hi = Do - 1;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int od = lo; od <= hi; ++od) {
+      int i0, i1;
+      float w1;
+      depth_src(od, Di, Do, i0, i1, w1);
+      float wgt = 0.f;
+      if (i0 == id) wgt += 1.f - w1;
+      if (i1 == id) wgt += w1;
+      if (wgt != 0.f) s += reinterpret_cast<const f32x4*>(dy)[((int64_t)n * Do + od) * plane + p] * wgt;
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------- misc
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
+                               int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                               float* __restrict__ dx, int64_t n4, int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = g[e] * act_grad(v[e], act, slope);
+    reinterpret_cast<f32x4*>(dx)[i] = o;
+  }
+}
+
+__global__ void channel_sum_kernel(const float* __restrict__ x, int ldx, int64_t rows, int C,
+                                   int64_t rows_per_block, double* __restrict__ scratch) {
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  column_reduce<1>(r_begin, r_end, C, scratch, 1, [&](int64_t row, int c, float(&acc)[1][4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][e] += v[e];
+  });
+}
+__global__ void channel_sum_finish_kernel(const double* __restrict__ scratch, float* __restrict__ out,
+                                          int C, int accumulate) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x)
+    out[c] = accumulate ? out[c] + (float)scratch[c] : (float)scratch[c];
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                     int ldy, int64_t rows, int C) {
+  const int c4n = C >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const int64_t row = i / c4n;
+    *reinterpret_cast<f32x4*>(y + row * ldy + c) = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+  }
+}
+
+// NCDHW <-> NDHWC through a 32x32 LDS tile (coalesced on both sides)
+__global__ void transpose_cs_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                    int64_t S, int to_nhwc) {
+  __shared__ float t[32][33];
+  const int n = blockIdx.z;
+  const int64_t s0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xn = x + (int64_t)n * C * S;
+  float* yn = y + (int64_t)n * C * S;
+  if (to_nhwc) {
+    for (int k = ty; k < 32; k += 8) {
+      const int c = c0 + k;
+      const int64_t s = s0 + tx;
+      t[k][tx] = (c < C && s < S) ? xn[(int64_t)c * S + s] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int64_t s = s0 + k;
+      const int c = c0 + tx;
+      if (c < C && s < S) yn[s * C + c] = t[tx][k];
+    }
+  } else {
+    for (int k = ty; k < 32; k += 8) {
+      const int64_t s = s0 + k;
+      const int c = c0 + tx;
+      t[k][tx] = (c < C && s < S) ? xn[s * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int c = c0 + k;
+      const int64_t s = s0 + tx;
+      if (c < C && s < S) yn[(int64_t)c * S + s] = t[tx][k];
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// blocks for a per-sample column reduction: cover S rows with <= ~1024 blocks/sample
+inline int64_t rows_per_block_for(int64_t S, int C, int N) {
+  const int rpp = EW_THREADS / (C / 4);
+  int64_t target_blocks = 2048 / (N > 0 ? N : 1);
+  if (target_blocks < 1) target_blocks = 1;
+  int64_t rpb = (S + target_blocks - 1) / target_blocks;
+  const int64_t min_rows = (int64_t)rpp * 8;
+  if (rpb < min_rows) rpb = min_rows;
+  return rpb;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int rehr_abi_version(void) { return 1; }
+
+extern "C" int rehr_pack_weights_f32(const float* in, float* out, int32_t A, int32_t Apad, int32_t B,
+                                     int32_t T, int32_t transpose_ab, void* stream) {
+  if (!in || !out || A < 1 || Apad < A || B < 1 || T < 1) return REHR_EINVAL;
+  const int64_t total = (int64_t)T * Apad * B;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, in, out, A,
+                     Apad, B, T, transpose_ab);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_se_gate_fwd_f32(const double* stats, const float* w, const float* b, float* gate,
+                                    float* mean, int32_t N, int32_t C, int64_t S, void* stream) {
+  if (!stats || !w || !b || !gate || !mean || N < 1 || C < 1 || S < 1 || N > 65535) return REHR_EINVAL;
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3((C + 3) / 4, N), dim3(256), 0, ST, stats, w, b, gate,
+                     mean, N, C, 1.0 / (double)S);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_scale_res_act_fwd_f32(const float* x, int32_t ldx, const float* gate,
+                                          const float* res, int32_t ldr, float* y, int32_t ldy,
+                                          int32_t N, int64_t S, int32_t C, int32_t act, float slope,
+                                          void* stream) {
+  if (!x || !gate || !y || N < 1 || S < 1 || C < 4 || C % 4 || ldx % 4 || ldy % 4 || (res && ldr % 4))
+    return REHR_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(gate) || (res && !aligned16(res))) return REHR_EINVAL;
+  const int64_t rows = (int64_t)N * S;
+  hipLaunchKernelGGL(scale_res_act_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
+                     x, ldx, gate, res, ldr, y, ldy, rows, S, C, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_scale_res_act_bwd_f32(const float* dy, int32_t lddy, const float* y, int32_t ldy,
+                                          const float* x, int32_t ldx, const float* gate, float* dx,
+                                          int32_t lddx, float* dres, int32_t lddr, double* dgate_acc,
+                                          int32_t N, int64_t S, int32_t C, int32_t act, float slope,
+                                          void* stream) {
+  if (!dy || !y || !x || !gate || !dx || !dgate_acc) return REHR_EINVAL;
+  if (N < 1 || N > 65535 || S < 1 || C < 4 || C % 4 || C > 1024) return REHR_EINVAL;
+  if (lddy % 4 || ldy % 4 || ldx % 4 || lddx % 4 || (dres && lddr % 4)) return REHR_EINVAL;
+  if (!aligned16(dy) || !aligned16(y) || !aligned16(x) || !aligned16(dx) || !aligned16(gate) ||
+      (dres && !aligned16(dres)))
+    return REHR_EINVAL;
+  const int64_t rpb = rows_per_block_for(S, C, N);
+  const int blocks = (int)((S + rpb - 1) / rpb);
+  hipLaunchKernelGGL(scale_res_act_bwd_kernel, dim3(blocks, N), dim3(EW_THREADS), 0, ST, dy, lddy, y,
+                     ldy, x, ldx, gate, dx, lddx, dres, lddr, dgate_acc, S, C, rpb, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_se_gate_bwd_f32(const double* dgate_acc, const float* gate, const float* mean,
+                                    const float* w, float* dw, float* db, float* kconst, int32_t N,
+                                    int32_t C, int64_t S, void* stream) {
+  if (!dgate_acc || !gate || !mean || !w || !dw || !db || !kconst || N < 1 || C < 1 || S < 1)
+    return REHR_EINVAL;
+  hipLaunchKernelGGL(se_gate_bwd_w_kernel, dim3(ew_blocks((int64_t)C * C)), dim3(EW_THREADS), 0, ST,
+                     dgate_acc, gate, mean, dw, db, N, C);
+  hipLaunchKernelGGL(se_gate_bwd_k_kernel, dim3(ew_blocks((int64_t)N * C)), dim3(EW_THREADS), 0, ST,
+                     dgate_acc, gate, w, kconst, N, C, (float)(1.0 / (double)S));
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_add_channel_const_f32(float* x, int32_t ldx, const float* k, int32_t N, int64_t S,
+                                          int32_t C, void* stream) {
+  if (!x || !k || N < 1 || S < 1 || C < 4 || C % 4 || ldx % 4 || !aligned16(x) || !aligned16(k))
+    return REHR_EINVAL;
+  const int64_t rows = (int64_t)N * S;
+  hipLaunchKernelGGL(add_channel_const_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
+                     x, ldx, k, rows, S, C);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_instnorm_act_fwd_f32(const float* x, int32_t ldx, const double* stats,
+                                         const float* gamma, const float* beta, float* y, int32_t ldy,
+                                         float* mean_rstd, int32_t N, int64_t S, int32_t C, float eps,
+                                         int32_t act, float slope, void* stream) {
+  if (!x || !stats || !gamma || !beta || !y || !mean_rstd) return REHR_EINVAL;
+  if (N < 1 || S < 1 || C < 4 || C % 4 || ldx % 4 || ldy % 4 || !aligned16(x) || !aligned16(y))
+    return REHR_EINVAL;
+  const int64_t NC = (int64_t)N * C;
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ew_blocks(NC)), dim3(EW_THREADS), 0, ST, stats,
+                     mean_rstd, NC, 1.0 / (double)S, eps);
+  const int64_t rows = (int64_t)N * S;
+  hipLaunchKernelGGL(instnorm_act_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
+                     x, ldx, mean_rstd, gamma, beta, y, ldy, rows, S, C, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_instnorm_act_bwd_f32(const float* dy, int32_t lddy, const float* x, int32_t ldx,
+                                         const float* mean_rstd, const float* gamma, const float* beta,
+                                         float* dx, int32_t lddx, float* dgamma, float* dbeta,
+                                         double* red, int32_t N, int64_t S, int32_t C, int32_t act,
+                                         float slope, void* stream) {
+  if (!dy || !x || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red) return REHR_EINVAL;
+  if (N < 1 || N > 65535 || S < 1 || C < 4 || C % 4 || C > 1024) return REHR_EINVAL;
+  if (lddy % 4 || ldx % 4 || lddx % 4 || !aligned16(dy) || !aligned16(x) || !aligned16(dx))
+    return REHR_EINVAL;
+  const int64_t rpb = rows_per_block_for(S, C, N);
+  const int blocks = (int)((S + rpb - 1) / rpb);
+  hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(blocks, N), dim3(EW_THREADS), 0, ST, dy, lddy, x,
+                     ldx, mean_rstd, gamma, beta, red, S, C, rpb, act, slope);
+  hipLaunchKernelGGL(instnorm_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, red, dgamma,
+                     dbeta, N, C);
+  const int64_t rows = (int64_t)N * S;
+  hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
+                     dy, lddy, x, ldx, mean_rstd, gamma, beta, red, dx, lddx, rows, S, C, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_upsample_depth_fwd_f32(const float* x, float* y, int32_t N, int32_t Di, int32_t Do,
+                                           int64_t HW, int32_t C, void* stream) {
+  if (!x || !y || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || !aligned16(x) || !aligned16(y))
+    return REHR_EINVAL;
+  const int64_t total = (int64_t)N * Do * HW * C / 4;
+  hipLaunchKernelGGL(upsample_depth_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, x, y, N,
+                     Di, Do, HW, C);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+extern "C" int rehr_upsample_depth_bwd_f32(const float* dy, float* dx, int32_t N, int32_t Di, int32_t Do,
+                                           int64_t HW, int32_t C, void* stream) {
+  if (!dy || !dx || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || !aligned16(dy) ||
+      !aligned16(dx))
+    return REHR_EINVAL;
+  const int64_t total = (int64_t)N * Di * HW * C / 4;
+  hipLaunchKernelGGL(upsample_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dy, dx,
+                     N, Di, Do, HW, C);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act, float slope,
+                                void* stream) {
+  if (!x || !y || n < 4 || n % 4 || !aligned16(x) || !aligned16(y)) return REHR_EINVAL;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, x, y, n / 4, act,
+                     slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+extern "C" int rehr_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int32_t act,
+                                float slope, void* stream) {
+  if (!dy || !y || !dx || n < 4 || n % 4 || !aligned16(dy) || !aligned16(y) || !aligned16(dx))
+    return REHR_EINVAL;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, dy, y, dx, n / 4,
+                     act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_channel_sum_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out,
+                                    int32_t accumulate, double* scratch, void* stream) {
+  if (!x || !out || !scratch || rows < 1 || C < 4 || C % 4 || C > 1024 || ldx % 4 || !aligned16(x))
+    return REHR_EINVAL;
+  if (hipMemsetAsync(scratch, 0, sizeof(double) * C, ST) != hipSuccess) return REHR_EHIP;
+  const int64_t rpb = rows_per_block_for(rows, C, 1);
+  const int blocks = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST, x, ldx, rows, C, rpb,
+                     scratch);
+  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, scratch, out, C,
+                     accumulate);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_copy_channels_f32(const float* x, int32_t ldx, float* y, int32_t ldy, int64_t rows,
+                                      int32_t C, void* stream) {
+  if (!x || !y || rows < 1 || C < 4 || C % 4 || ldx % 4 || ldy % 4 || !aligned16(x) || !aligned16(y))
+    return REHR_EINVAL;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST, x,
+                     ldx, y, ldy, rows, C);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_nchw_to_nhwc_f32(const float* x, float* y, int32_t N, int32_t C, int64_t S,
+                                     void* stream) {
+  if (!x || !y || N < 1 || N > 65535 || C < 1 || S < 1 || (C + 31) / 32 > 65535) return REHR_EINVAL;
+  hipLaunchKernelGGL(transpose_cs_kernel, dim3((unsigned)((S + 31) / 32), (C + 31) / 32, N), dim3(256), 0,
+                     ST, x, y, C, S, 1);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+extern "C" int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_t C, int64_t S,
+                                     void* stream) {
+  if (!x || !y || N < 1 || N > 65535 || C < 1 || S < 1 || (C + 31) / 32 > 65535) return REHR_EINVAL;
+  hipLaunchKernelGGL(transpose_cs_kernel, dim3((unsigned)((S + 31) / 32), (C + 31) / 32, N), dim3(256), 0,
+                     ST, x, y, C, S, 0);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}

@@ -1,0 +1,312 @@
+// Gather-GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// One kernel family computes every wide-channel convolution of the hot path:
+// Conv3d forward, Conv3d input gradient (per stride phase), ConvTranspose3d
+// forward (per stride phase) and its input gradient, Conv2d (D == 1) -- see
+// rehr_gather_gemm_desc in include/rehrseg_hip.h for the contraction.
+//
+// Design (MI355X first):
+//  * implicit GEMM, M = 128 lattice voxels of one sample (a td x th x tw brick
+//    so the 27-tap halo of a tile stays in the XCD's L2), N = 32/64/128 output
+//    channels, K = taps x 32-channel chunks.  NDHWC makes every A row a
+//    contiguous 128-byte line; taps of one chunk are visited back to back so
+//    the shifted re-reads hit L1/L2, not HBM.
+//  * fp32 MFMA is exact fp32 (fmaf chain) at the vector-peak rate, 64 cycles per
+//    32x32x2 instruction; one accumulator chain per wave already saturates the
+//    pipe, so a plain register-staged double buffer (global -> VGPR -> LDS, one
+//    barrier per K step) is enough to keep it fed.
+//  * both operands sit in LDS as [row][32 k] with a 36-float row stride:
+//    ds_read_b128 of 4 consecutive k per lane is bank-conflict free, and one
+//    128-bit read feeds four MFMA k-steps (the k order inside a step is the
+//    same permutation for A and B, which a dot product does not care about).
+//  * epilogue fuses bias, ReLU/LeakyReLU and the per-(sample, channel) sum /
+//    sum-of-squares that SEGating's pool and InstanceNorm3d need (double
+//    atomics, one per channel per wave).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;       // channels per K step
+constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
+constexpr int NTHREADS = 256;
+
+struct GGParams {
+  rehr_gather_gemm_desc d;
+  int tiles_d, tiles_h, tiles_w, m_tiles, n_tiles;
+  int kchunks;  // Cin / 32
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams p) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int FM = WTM / 32, FN = WTN / 32;
+  constexpr int AROWS = BM / 32, BROWS = BN / 32;  // rows per thread per tile
+  static_assert(WGM * WGN == 4, "4 waves");
+  const rehr_gather_gemm_desc& d = p.d;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                               // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;             // [2][BN][LDS_LD]
+  int* row_out = (int*)(Bs + 2 * BN * LDS_LD);    // [BM] destination voxel or -1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int n_img = blockIdx.y;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = logical / p.n_tiles;
+  const int nt = logical - mt * p.n_tiles;
+  const int n0 = nt * BN;
+
+  // tile origin on the lattice (brick mode), or flattened run (tile_d == 0)
+  const bool linear = d.tile_d == 0;
+  const int tx = mt % p.tiles_w;
+  const int ty = (mt / p.tiles_w) % p.tiles_h;
+  const int tz = mt / (p.tiles_w * p.tiles_h);
+  const int thw = linear ? 1 : d.tile_h * d.tile_w;
+  const int lhw = d.Lh * d.Lw;
+  auto row_coords = [&](int r, int& od, int& oh, int& ow) -> bool {
+    if (linear) {
+      const int flat = mt * BM + r;
+      od = flat / lhw;
+      const int rem = flat - od * lhw;
+      oh = rem / d.Lw;
+      ow = rem - oh * d.Lw;
+      return od < d.Ld;
+    }
+    const int ld_ = r / thw, rem = r - ld_ * thw;
+    const int lh_ = rem / d.tile_w, lw_ = rem - lh_ * d.tile_w;
+    od = tz * d.tile_d + ld_;
+    oh = ty * d.tile_h + lh_;
+    ow = tx * d.tile_w + lw_;
+    return od < d.Ld && oh < d.Lh && ow < d.Lw;
+  };
+
+  // destination offsets of the tile rows (used by the epilogue)
+  if (tid < BM) {
+    int od, oh, ow;
+    int off = -1;
+    if (row_coords(tid, od, oh, ow)) {
+      const int yd = od * d.osd + d.obd, yh = oh * d.osh + d.obh, yw = ow * d.osw + d.obw;
+      off = ((n_img * d.Dy + yd) * d.Hy + yh) * d.Wy + yw;
+    }
+    row_out[tid] = off;
+  }
+
+  // per-thread gather state: rows r0 + 32*i, 16-byte chunk q of the 128-byte row
+  const int q = tid & 7, r0 = tid >> 3;
+  int sd0[AROWS], sh0[AROWS], sw0[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    int od, oh, ow;
+    const bool ok = row_coords(r0 + 32 * i, od, oh, ow);
+    // an invalid row gets a base far outside the source so every tap misses
+    sd0[i] = ok ? od * d.sd + d.bd : -(1 << 28);
+    sh0[i] = oh * d.sh + d.bh;
+    sw0[i] = ow * d.sw + d.bw;
+  }
+  const int64_t img_vox = (int64_t)n_img * d.Di * d.Hi * d.Wi;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // K-step iterator: channel chunk outermost, then jd, jh, jw (innermost)
+  int cc = 0, jd = 0, jh = 0, jw = 0;
+  const int nsteps = p.kchunks * d.td.count * d.th.count * d.tw.count;
+
+  f32x4 ra[AROWS], rb[BROWS];
+
+  auto issue_loads = [&]() {
+    const int dd = d.td.off0 + d.td.offs * jd;
+    const int dh = d.th.off0 + d.th.offs * jh;
+    const int dw = d.tw.off0 + d.tw.offs * jw;
+    const float* src;
+    int ld, coff;
+    if (cc < d.c1) { src = d.x1; ld = d.ldx1; coff = cc; }
+    else           { src = d.x2; ld = d.ldx2; coff = cc - d.c1; }
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int id = sd0[i] + dd, ih = sh0[i] + dh, iw = sw0[i] + dw;
+      const bool inb = (unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi &&
+                       (unsigned)iw < (unsigned)d.Wi;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (inb) {
+        const int64_t vox = img_vox + ((int64_t)id * d.Hi + ih) * d.Wi + iw;
+        v = *reinterpret_cast<const f32x4*>(src + vox * ld + coff + q * 4);
+      }
+      ra[i] = v;
+    }
+    const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW +
+                   (d.tw.k0 + d.tw.ks * jw);
+    const float* wbase = d.wp + ((int64_t)wt * d.Npad + n0) * d.Cin + cc + q * 4;
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(wbase + (int64_t)(r0 + 32 * i) * d.Cin);
+    // advance iterator
+    if (++jw == d.tw.count) {
+      jw = 0;
+      if (++jh == d.th.count) {
+        jh = 0;
+        if (++jd == d.td.count) { jd = 0; cc += BK; }
+      }
+    }
+  };
+  auto commit_loads = [&](int buf) {
+    float* a = As + buf * BM * LDS_LD;
+    float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i)
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDS_LD + q * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i)
+      *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDS_LD + q * 4) = rb[i];
+  };
+
+  issue_loads();
+  commit_loads(0);
+  __syncthreads();
+
+  const int arow = wm * WTM + (lane & 31);
+  const int brow = wn * WTN + (lane & 31);
+  const int koff = 4 * (lane >> 5);
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    const bool more = (s + 1) < nsteps;
+    if (more) issue_loads();
+
+    const float* a = As + buf * BM * LDS_LD;
+    const float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 fa[FM], fb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(a + (arow + 32 * i) * LDS_LD + kk * 8 + koff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        fb[j] = *reinterpret_cast<const f32x4*>(b + (brow + 32 * j) * LDS_LD + kk * 8 + koff);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) commit_loads(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation + store (+ statistics) ----
+  const int chalf = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+    const bool colok = col < d.Cout;
+    const float bv = (d.bias != nullptr && colok) ? d.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+        const int off = row_out[row];
+        float v = apply_act(acc[i][j][r] + bv, d.act, d.slope);
+        if (off >= 0 && colok) {
+          d.y[(int64_t)off * d.ldy + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (d.stats_mode != 0) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (chalf == 0 && colok) {
+        double* st = d.stats + ((int64_t)n_img * d.Cout + col) * 2;
+        atomicAdd(st, (double)s1);
+        if (d.stats_mode == 2) atomicAdd(st + 1, (double)s2);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_gg(const GGParams& p, hipStream_t stream) {
+  const size_t smem = (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(float) + BM * sizeof(int);
+  static bool attr_set = false;
+  auto kern = gather_gemm_kernel<BM, BN, WGM, WGN>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return REHR_EHIP;
+    attr_set = true;
+  }
+  dim3 grid(p.m_tiles * p.n_tiles, p.d.N, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, stream, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+bool taps_ok(const rehr_axis_taps& t) { return t.count >= 1; }
+
+}  // namespace
+
+extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* stream) {
+  if (dp == nullptr) return REHR_EINVAL;
+  const rehr_gather_gemm_desc& d = *dp;
+  if (!d.x1 || !d.wp || !d.y) return REHR_EINVAL;
+  if (d.N < 1 || d.Cin < 32 || d.Cin % 32 || d.c1 % 32 || d.c1 < 0 || d.c1 > d.Cin) return REHR_EINVAL;
+  if (d.c1 < d.Cin && !d.x2) return REHR_EINVAL;
+  if (d.c1 == 0) return REHR_EINVAL;
+  if (d.ldx1 % 4 || (d.x2 && d.ldx2 % 4)) return REHR_EINVAL;
+  if (((uintptr_t)d.x1 | (uintptr_t)d.wp | (uintptr_t)(d.x2 ? d.x2 : d.x1)) & 15) return REHR_EINVAL;
+  if (d.Npad % 32 || d.Npad < d.Cout || d.Cout < 1) return REHR_EINVAL;
+  if (d.Ld < 1 || d.Lh < 1 || d.Lw < 1) return REHR_EINVAL;
+  if (!taps_ok(d.td) || !taps_ok(d.th) || !taps_ok(d.tw)) return REHR_EINVAL;
+  if (d.tile_d != 0 &&
+      (d.tile_d < 1 || d.tile_h < 1 || d.tile_w < 1 || d.tile_d * d.tile_h * d.tile_w != 128))
+    return REHR_EINVAL;
+  if (d.stats_mode != 0 && !d.stats) return REHR_EINVAL;
+  if (d.N > 65535) return REHR_EINVAL;
+  // destination extent check: the last lattice point must land inside y
+  {
+    const int64_t yd = (int64_t)(d.Ld - 1) * d.osd + d.obd, yh = (int64_t)(d.Lh - 1) * d.osh + d.obh,
+                  yw = (int64_t)(d.Lw - 1) * d.osw + d.obw;
+    if (d.obd < 0 || d.obh < 0 || d.obw < 0 || yd >= d.Dy || yh >= d.Hy || yw >= d.Wy) return REHR_EINVAL;
+    if (d.ldy < d.Cout) return REHR_EINVAL;
+    if ((int64_t)d.N * d.Dy * d.Hy * d.Wy >= (1ll << 31)) return REHR_EINVAL;
+  }
+
+  GGParams p;
+  p.d = d;
+  if (d.tile_d == 0) {
+    p.tiles_d = p.tiles_h = 1;
+    p.tiles_w = (int)(((int64_t)d.Ld * d.Lh * d.Lw + 127) / 128);
+    p.m_tiles = p.tiles_w;
+  } else {
+    p.tiles_d = (d.Ld + d.tile_d - 1) / d.tile_d;
+    p.tiles_h = (d.Lh + d.tile_h - 1) / d.tile_h;
+    p.tiles_w = (d.Lw + d.tile_w - 1) / d.tile_w;
+    p.m_tiles = p.tiles_d * p.tiles_h * p.tiles_w;
+  }
+  p.kchunks = d.Cin / 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (d.Npad % 128 == 0) {
+    p.n_tiles = d.Npad / 128;
+    return launch_gg<128, 128, 2, 2>(p, st);
+  } else if (d.Npad % 64 == 0) {
+    p.n_tiles = d.Npad / 64;
+    return launch_gg<128, 64, 2, 2>(p, st);
+  } else {
+    p.n_tiles = d.Npad / 32;
+    return launch_gg<128, 32, 4, 1>(p, st);
+  }
+}

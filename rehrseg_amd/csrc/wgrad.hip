@@ -1,0 +1,340 @@
+// Weight gradient on the fp32 matrix cores (see rehr_wgrad_desc).
+//
+//   dst[a][c][tap] = sum over (sample, lattice voxel v)  L[v][a] * G[src(v,tap)][c]
+//
+// GEMM view per tap: M = lattice channels a, N = gathered channels c, K = all
+// lattice voxels of the batch.  K is huge (up to 2M voxels) and M x N is small,
+// so the grid is (tap, a-tile, c-tile) x K-splits; every split writes its
+// partial tile to a workspace slab with plain stores and a second kernel sums
+// the slabs in a fixed order (bitwise reproducible, unlike float atomics) while
+// transposing to the torch parameter layout.
+//
+// Both operands arrive voxel-major ([voxel][channel], channel contiguous), which
+// is exactly the MFMA A/B register order for k = voxel: lane l reads
+// tile[k = 2*step + (l>>5)][i = l&31] with a conflict-free ds_read_b32, no
+// transposition anywhere.
+#include "common.h"
+
+namespace {
+
+constexpr int BKV = 32;  // lattice voxels per K step
+constexpr int NTHREADS = 256;
+
+struct WGParams {
+  rehr_wgrad_desc d;
+  int a_tiles, c_tiles, T;
+  int64_t kv_total;   // N * Ld*Lh*Lw
+  int64_t kv_per_split;
+  int splits;
+  int Capad, Cgpad;   // tile-padded channel counts of the slab
+  float* slab_bias;   // [splits][Ca] or null
+};
+
+// BA x BG output tile, 4 waves as WGA x WGG
+template <int BA, int BG, int WGA, int WGG>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
+  constexpr int WTA = BA / WGA, WTG = BG / WGG;
+  constexpr int FA = WTA / 32, FG = WTG / 32;
+  constexpr int LDA = BA + 4, LDG = BG + 4;
+  constexpr int A_TPR = BA / 4, G_TPR = BG / 4;          // threads per row
+  constexpr int A_RPP = NTHREADS / A_TPR, G_RPP = NTHREADS / G_TPR;  // rows per pass
+  constexpr int A_PASS = BKV / A_RPP, G_PASS = BKV / G_RPP;
+  constexpr int WGK = 4 / (WGA * WGG);  // waves sharing one output tile, splitting K
+  static_assert(WGA * WGG * WGK == 4, "4 waves");
+  constexpr int KSTEPS = (BKV / 2) / WGK;  // MFMA k-steps per wave per K tile
+  const rehr_wgrad_desc& d = p.d;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ls = smem;                    // [2][BKV][LDA]
+  float* Gs = smem + 2 * BKV * LDA;    // [2][BKV][LDG]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WGA * WGG);
+  const int wa = (wave % (WGA * WGG)) / WGG, wg = wave % WGG;
+
+  // block -> (tap, a tile, c tile); c fastest so blocks sharing L rows are neighbours
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = b % p.c_tiles; b /= p.c_tiles;
+  const int at = b % p.a_tiles; b /= p.a_tiles;
+  const int tap = b;
+  const int jw = tap % d.tw.count;
+  const int jh = (tap / d.tw.count) % d.th.count;
+  const int jd = tap / (d.tw.count * d.th.count);
+  const int dd = d.td.off0 + d.td.offs * jd, dh = d.th.off0 + d.th.offs * jh,
+            dw = d.tw.off0 + d.tw.offs * jw;
+  const int a0 = at * BA, c0 = ct * BG;
+  const int split = blockIdx.y;
+  const int64_t v_begin = (int64_t)split * p.kv_per_split;
+  int64_t v_end = v_begin + p.kv_per_split;
+  if (v_end > p.kv_total) v_end = p.kv_total;
+  const int lhw = d.Lh * d.Lw;
+  const int lvox = d.Ld * lhw;
+
+  f32x16 acc[FA][FG];
+#pragma unroll
+  for (int i = 0; i < FA; ++i)
+#pragma unroll
+    for (int j = 0; j < FG; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[FA];
+#pragma unroll
+  for (int i = 0; i < FA; ++i) bsum[i] = 0.f;
+  const bool do_bias = (p.slab_bias != nullptr) && tap == 0 && ct == 0 && wg == 0;  // every wk
+
+  f32x4 rl[A_PASS], rg[G_PASS];
+  const int aq = tid % A_TPR, ar = tid / A_TPR;
+  const int gq = tid % G_TPR, gr = tid / G_TPR;
+  const bool a_col_ok = (a0 + aq * 4) < d.Ca;   // Ca % 32 == 0 and tiles are 32-multiples
+  const bool g_col_ok = (c0 + gq * 4) < d.Cg;
+
+  auto issue_loads = [&](int64_t vbase) {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const int64_t v = vbase + ar + i * A_RPP;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (v < v_end && a_col_ok) x = *reinterpret_cast<const f32x4*>(d.l + v * d.ldl + a0 + aq * 4);
+      rl[i] = x;
+    }
+#pragma unroll
+    for (int i = 0; i < G_PASS; ++i) {
+      const int64_t v = vbase + gr + i * G_RPP;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (v < v_end && g_col_ok) {
+        const int n = (int)(v / lvox);
+        int rem = (int)(v - (int64_t)n * lvox);
+        const int od = rem / lhw; rem -= od * lhw;
+        const int oh = rem / d.Lw, ow = rem - oh * d.Lw;
+        const int id = od * d.sd + d.bd + dd, ih = oh * d.sh + d.bh + dh, iw = ow * d.sw + d.bw + dw;
+        if ((unsigned)id < (unsigned)d.Dg && (unsigned)ih < (unsigned)d.Hg && (unsigned)iw < (unsigned)d.Wg) {
+          const int64_t gv = (((int64_t)n * d.Dg + id) * d.Hg + ih) * d.Wg + iw;
+          x = *reinterpret_cast<const f32x4*>(d.g + gv * d.ldg + c0 + gq * 4);
+        }
+      }
+      rg[i] = x;
+    }
+  };
+  auto commit_loads = [&](int buf) {
+    float* l = Ls + buf * BKV * LDA;
+    float* g = Gs + buf * BKV * LDG;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i)
+      *reinterpret_cast<f32x4*>(l + (ar + i * A_RPP) * LDA + aq * 4) = rl[i];
+#pragma unroll
+    for (int i = 0; i < G_PASS; ++i)
+      *reinterpret_cast<f32x4*>(g + (gr + i * G_RPP) * LDG + gq * 4) = rg[i];
+  };
+
+  const int64_t nsteps = (v_end > v_begin) ? (v_end - v_begin + BKV - 1) / BKV : 0;
+  if (nsteps > 0) {
+    issue_loads(v_begin);
+    commit_loads(0);
+  }
+  __syncthreads();
+
+  const int acol = wa * WTA + (lane & 31);
+  const int gcol = wg * WTG + (lane & 31);
+  const int krow = lane >> 5;
+
+  for (int64_t s = 0; s < nsteps; ++s) {
+    const int buf = (int)(s & 1);
+    const bool more = (s + 1) < nsteps;
+    if (more) issue_loads(v_begin + (s + 1) * BKV);
+    const float* l = Ls + buf * BKV * LDA;
+    const float* g = Gs + buf * BKV * LDG;
+#pragma unroll
+    for (int kk = wk * KSTEPS; kk < (wk + 1) * KSTEPS; ++kk) {
+      float fa[FA], fg[FG];
+#pragma unroll
+      for (int i = 0; i < FA; ++i) fa[i] = l[(kk * 2 + krow) * LDA + acol + 32 * i];
+#pragma unroll
+      for (int j = 0; j < FG; ++j) fg[j] = g[(kk * 2 + krow) * LDG + gcol + 32 * j];
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < FA; ++i) bsum[i] += fa[i];
+      }
+#pragma unroll
+      for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FG; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fg[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) commit_loads(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (WGK > 1) {
+    // waves that split K combine through LDS (the staging buffers are free now)
+    float* red = smem;  // [WGK-1][FA*FG*16 + FA][64]
+    constexpr int PER = FA * FG * 16 + FA;
+    if (wk > 0) {
+      float* o = red + (int64_t)(wk - 1) * PER * 64;
+#pragma unroll
+      for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FG; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[((i * FG + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+#pragma unroll
+      for (int i = 0; i < FA; ++i) o[(FA * FG * 16 + i) * 64 + lane] = bsum[i];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+    for (int k = 0; k < WGK - 1; ++k) {
+      const float* o = red + (int64_t)k * PER * 64;
+#pragma unroll
+      for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FG; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += o[((i * FG + j) * 16 + r) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < FA; ++i) bsum[i] += o[(FA * FG * 16 + i) * 64 + lane];
+    }
+  }
+  // partial tile -> slab[split][tap][Capad][Cgpad]
+  float* slab = d.workspace + (((int64_t)split * p.T + tap) * p.Capad) * p.Cgpad;
+  const int chalf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < FA; ++i)
+#pragma unroll
+    for (int j = 0; j < FG; ++j) {
+      const int col = c0 + wg * WTG + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * WTA + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+        slab[(int64_t)row * p.Cgpad + col] = acc[i][j][r];
+      }
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+      float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      const int row = a0 + wa * WTA + i * 32 + (lane & 31);
+      if (chalf == 0 && row < d.Ca) p.slab_bias[(int64_t)split * d.Ca + row] = v;
+    }
+  }
+}
+
+// dst[a*sa + c*sc + wt*st] (+)= sum_split slab[split][tap][a][c]
+__global__ void wgrad_reduce_kernel(const WGParams p) {
+  const rehr_wgrad_desc& d = p.d;
+  const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
+  const int64_t slab_sz = (int64_t)p.T * p.Capad * p.Cgpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d.Cg);
+    const int64_t r = i / d.Cg;
+    const int a = (int)(r % d.Ca);
+    const int tap = (int)(r / d.Ca);
+    const float* s = d.workspace + ((int64_t)tap * p.Capad + a) * p.Cgpad + c;
+    float sum = 0.f;
+    for (int k = 0; k < p.splits; ++k) sum += s[(int64_t)k * slab_sz];
+    const int jw = tap % d.tw.count;
+    const int jh = (tap / d.tw.count) % d.th.count;
+    const int jd = tap / (d.tw.count * d.th.count);
+    const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW +
+                   (d.tw.k0 + d.tw.ks * jw);
+    float* o = d.dst + a * d.dst_sa + c * d.dst_sc + wt * d.dst_st;
+    *o = d.accumulate ? (*o + sum) : sum;
+  }
+  if (p.slab_bias != nullptr && d.dbias != nullptr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.Ca;
+         i += (int64_t)gridDim.x * blockDim.x) {
+      float sum = 0.f;
+      for (int k = 0; k < p.splits; ++k) sum += p.slab_bias[(int64_t)k * d.Ca + i];
+      d.dbias[i] = d.accumulate ? (d.dbias[i] + sum) : sum;
+    }
+  }
+}
+
+int tile_for(int c) { return (c % 128 == 0) ? 128 : ((c % 64 == 0) ? 64 : 32); }
+
+bool plan(const rehr_wgrad_desc& d, WGParams& p) {
+  if (!d.l || !d.g || !d.dst) return false;
+  if (d.Ca < 32 || d.Ca % 32 || d.Cg < 32 || d.Cg % 32) return false;
+  if (d.ldl % 4 || d.ldg % 4) return false;
+  if (((uintptr_t)d.l | (uintptr_t)d.g) & 15) return false;
+  if (d.N < 1 || d.Ld < 1 || d.Lh < 1 || d.Lw < 1) return false;
+  if (d.td.count < 1 || d.th.count < 1 || d.tw.count < 1) return false;
+  p.d = d;
+  p.T = d.td.count * d.th.count * d.tw.count;
+  // one tile size for both operands keeps the instantiation count small
+  int t = tile_for(d.Ca);
+  const int tg = tile_for(d.Cg);
+  if (tg < t) t = tg;
+  p.a_tiles = (d.Ca + t - 1) / t;
+  p.c_tiles = (d.Cg + t - 1) / t;
+  p.Capad = p.a_tiles * t;
+  p.Cgpad = p.c_tiles * t;
+  p.kv_total = (int64_t)d.N * d.Ld * d.Lh * d.Lw;
+  const int64_t tiles = (int64_t)p.T * p.a_tiles * p.c_tiles;
+  // aim for ~4 blocks per CU-slot (256 CUs x 2 resident) with >= 16 K steps each
+  int64_t want = (2048 + tiles - 1) / tiles;
+  const int64_t max_by_k = (p.kv_total + 16 * BKV - 1) / (16 * BKV);
+  if (want > max_by_k) want = max_by_k;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  int64_t per = (p.kv_total + want - 1) / want;
+  per = (per + BKV - 1) / BKV * BKV;
+  p.kv_per_split = per;
+  p.splits = (int)((p.kv_total + per - 1) / per);
+  return true;
+}
+
+int64_t ws_bytes(const WGParams& p) {
+  int64_t f = (int64_t)p.splits * p.T * p.Capad * p.Cgpad;
+  f += (int64_t)p.splits * p.d.Ca;  // bias slab
+  return f * (int64_t)sizeof(float);
+}
+
+template <int B, int WGA, int WGG>
+int launch_wg(const WGParams& p, hipStream_t stream) {
+  const size_t smem = (size_t)2 * BKV * ((B + 4) + (B + 4)) * sizeof(float);
+  auto kern = wgrad_kernel<B, B, WGA, WGG>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return REHR_EHIP;
+    attr_set = true;
+  }
+  dim3 grid(p.T * p.a_tiles * p.c_tiles, p.splits, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, stream, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* dp) {
+  if (!dp) return REHR_EINVAL;
+  WGParams p;
+  rehr_wgrad_desc d = *dp;
+  if (!d.dst) d.dst = reinterpret_cast<float*>(16);  // size query may come before allocation
+  if (!plan(d, p)) return REHR_EINVAL;
+  return ws_bytes(p);
+}
+
+extern "C" int rehr_wgrad_f32(const rehr_wgrad_desc* dp, void* stream) {
+  if (!dp) return REHR_EINVAL;
+  WGParams p;
+  if (!plan(*dp, p)) return REHR_EINVAL;
+  const rehr_wgrad_desc& d = p.d;
+  if (!d.workspace || d.workspace_bytes < ws_bytes(p)) return REHR_EINVAL;
+  if (p.splits > 65535) return REHR_EINVAL;
+  p.slab_bias = d.dbias ? d.workspace + (int64_t)p.splits * p.T * p.Capad * p.Cgpad : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int t = p.Capad / p.a_tiles;
+  int rc;
+  if (t == 128) rc = launch_wg<128, 2, 2>(p, st);
+  else if (t == 64) rc = launch_wg<64, 2, 2>(p, st);
+  else rc = launch_wg<32, 1, 1>(p, st);
+  if (rc != REHR_OK) return rc;
+  const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}

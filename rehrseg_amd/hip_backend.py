@@ -1,0 +1,259 @@
+"""Launch layer: turns torch tensors into the plain-pointer descriptors of the
+C-ABI (include/rehrseg_hip.h) and launches on torch's current HIP stream.
+
+Every activation handed to this module is a 5-D torch tensor with logical shape
+(N, C, D, H, W) whose memory is NDHWC-dense (``ops.to_cl``).  PyTorch is used for
+device memory and streams only; all arithmetic happens in librehrseg_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+name = "hip"
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _taps(t):
+    return L.AxisTaps(*t)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise L.RehrsegHipError("librehrseg_hip.so needs device tensors (no CPU fallback)")
+        if t.dtype not in (torch.float32, torch.float64):
+            raise L.RehrsegHipError(f"unsupported dtype {t.dtype}")
+
+
+def new_act(N, Cc, D, H, W, like, zero=False):
+    t = torch.empty((N, Cc, D, H, W), dtype=torch.float32, device=like.device, memory_format=torch.channels_last_3d)
+    return t.zero_() if zero else t
+
+
+def pack_weights(w, A, Apad, B, T, transpose):
+    _chk_dev(w)
+    w = w.contiguous()
+    out = torch.empty((T, Apad, B), dtype=torch.float32, device=w.device)
+    L.check(L.load().rehr_pack_weights_f32(_ptr(w), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
+            "rehr_pack_weights_f32")
+    return out
+
+
+def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
+                os_, ob, bias, act, slope, stats, stats_mode, tile):
+    _chk_dev(x1, x2, wp, y, bias, stats)
+    d = L.GatherGemmDesc()
+    d.x1, d.x2, d.c1 = _ptr(x1), _ptr(x2), c1
+    d.ldx1 = x1.shape[1]
+    d.ldx2 = x2.shape[1] if x2 is not None else 0
+    d.N = x1.shape[0]
+    d.Di, d.Hi, d.Wi = src_dims
+    d.Cin = Cin
+    d.Ld, d.Lh, d.Lw = lattice
+    d.sd, d.sh, d.sw = s
+    d.bd, d.bh, d.bw = b
+    d.td, d.th, d.tw = _taps(taps[0]), _taps(taps[1]), _taps(taps[2])
+    d.KH, d.KW = KH, KW
+    d.wp, d.Npad = _ptr(wp), Npad
+    d.y = _ptr(y)
+    d.Dy, d.Hy, d.Wy = y_dims
+    d.Cout, d.ldy = Cout, y.shape[1]
+    d.osd, d.osh, d.osw = os_
+    d.obd, d.obh, d.obw = ob
+    d.bias, d.act, d.slope = _ptr(bias), act, slope
+    d.stats, d.stats_mode = _ptr(stats), stats_mode
+    d.tile_d, d.tile_h, d.tile_w = tile
+    L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
+
+
+def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):
+    _chk_dev(l, g, dst, dbias)
+    d = L.WgradDesc()
+    d.l, d.ldl, d.Ca = _ptr(l), l.shape[1], Ca
+    d.g, d.ldg, d.Cg = _ptr(g), g.shape[1], Cg
+    d.N = N
+    d.Ld, d.Lh, d.Lw = lattice
+    d.Dg, d.Hg, d.Wg = g_dims
+    d.sd, d.sh, d.sw = s
+    d.bd, d.bh, d.bw = b
+    d.td, d.th, d.tw = _taps(taps[0]), _taps(taps[1]), _taps(taps[2])
+    d.KH, d.KW = KH, KW
+    d.dst = C.c_void_p(dst.data_ptr() + 4 * dst_off)
+    d.dst_sa, d.dst_sc, d.dst_st = dst_strides
+    d.accumulate = int(accumulate)
+    d.dbias = _ptr(dbias)
+    lib = L.load()
+    nbytes = lib.rehr_wgrad_workspace_bytes(C.byref(d))
+    if nbytes < 0:
+        L.check(int(nbytes), "rehr_wgrad_workspace_bytes")
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
+    d.workspace, d.workspace_bytes = _ptr(ws), nbytes
+    L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
+
+
+def _direct_desc(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
+    d = L.DirectConvDesc()
+    N, Cin, Di, Hi, Wi = x.shape
+    Cout, _, KD, KH, KW = w.shape
+    _, _, Do, Ho, Wo = y.shape
+    d.x, d.ldx, d.N, d.Di, d.Hi, d.Wi, d.Cin = _ptr(x), Cin, N, Di, Hi, Wi, Cin
+    d.w, d.bias = _ptr(w), _ptr(bias)
+    d.y, d.ldy, d.Do, d.Ho, d.Wo, d.Cout = _ptr(y), Cout, Do, Ho, Wo, Cout
+    d.KD, d.KH, d.KW = KD, KH, KW
+    d.sd, d.sh, d.sw = stride
+    d.pd, d.ph, d.pw = pad
+    d.act, d.slope = act, slope
+    d.stats, d.stats_mode = _ptr(stats), stats_mode
+    return d
+
+
+def small_cin_fwd(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
+    _chk_dev(x, w, bias, y, stats)
+    d = _direct_desc(x, w.contiguous(), bias, y, stride, pad, act, slope, stats, stats_mode)
+    L.check(L.load().rehr_conv_small_cin_fwd_f32(C.byref(d), _stream()), "rehr_conv_small_cin_fwd_f32")
+
+
+def small_cin_wgrad(x, w, dy, stride, pad, want_bias):
+    _chk_dev(x, w, dy)
+    d = _direct_desc(x, w.contiguous(), None, dy, stride, pad, 0, 0.0, None, 0)
+    lib = L.load()
+    nbytes = lib.rehr_conv_small_cin_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+    db = torch.empty(w.shape[0], dtype=torch.float32, device=x.device) if want_bias else None
+    L.check(lib.rehr_conv_small_cin_wgrad_f32(C.byref(d), _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream()),
+            "rehr_conv_small_cin_wgrad_f32")
+    return dw, db
+
+
+def se_gate_fwd(stats, w, b, N, Cc, S):
+    _chk_dev(stats, w, b)
+    gate = torch.empty((N, Cc), dtype=torch.float32, device=stats.device)
+    mean = torch.empty((N, Cc), dtype=torch.float32, device=stats.device)
+    L.check(L.load().rehr_se_gate_fwd_f32(_ptr(stats), _ptr(w.contiguous()), _ptr(b.contiguous()), _ptr(gate),
+                                          _ptr(mean), N, Cc, S, _stream()), "rehr_se_gate_fwd_f32")
+    return gate, mean
+
+
+def _nsc(x):
+    N, Cc, D, H, W = x.shape
+    return N, D * H * W, Cc
+
+
+def scale_res_act_fwd(x, gate, res, act, slope):
+    _chk_dev(x, gate, res)
+    N, S, Cc = _nsc(x)
+    y = new_act(*x.shape, like=x)
+    L.check(L.load().rehr_scale_res_act_fwd_f32(_ptr(x), Cc, _ptr(gate), _ptr(res), Cc, _ptr(y), Cc, N, S, Cc,
+                                                act, slope, _stream()), "rehr_scale_res_act_fwd_f32")
+    return y
+
+
+def scale_res_act_bwd(dy, y, x, gate, want_dres, act, slope):
+    _chk_dev(dy, y, x, gate)
+    N, S, Cc = _nsc(x)
+    dx = new_act(*x.shape, like=x)
+    dres = new_act(*x.shape, like=x) if want_dres else None
+    dgate = torch.zeros((N, Cc), dtype=torch.float64, device=x.device)
+    L.check(L.load().rehr_scale_res_act_bwd_f32(_ptr(dy), Cc, _ptr(y), Cc, _ptr(x), Cc, _ptr(gate), _ptr(dx), Cc,
+                                                _ptr(dres), Cc, _ptr(dgate), N, S, Cc, act, slope, _stream()),
+            "rehr_scale_res_act_bwd_f32")
+    return dx, dres, dgate
+
+
+def se_gate_bwd(dgate, gate, mean, w, S):
+    _chk_dev(dgate, gate, mean, w)
+    N, Cc = gate.shape
+    dw = torch.empty((Cc, Cc), dtype=torch.float32, device=gate.device)
+    db = torch.empty((Cc,), dtype=torch.float32, device=gate.device)
+    k = torch.empty((N, Cc), dtype=torch.float32, device=gate.device)
+    L.check(L.load().rehr_se_gate_bwd_f32(_ptr(dgate), _ptr(gate), _ptr(mean), _ptr(w.contiguous()), _ptr(dw),
+                                          _ptr(db), _ptr(k), N, Cc, S, _stream()), "rehr_se_gate_bwd_f32")
+    return dw, db, k
+
+
+def add_channel_const(x, k):
+    _chk_dev(x, k)
+    N, S, Cc = _nsc(x)
+    L.check(L.load().rehr_add_channel_const_f32(_ptr(x), Cc, _ptr(k), N, S, Cc, _stream()),
+            "rehr_add_channel_const_f32")
+
+
+def instnorm_act_fwd(x, stats, gamma, beta, eps, act, slope):
+    _chk_dev(x, stats, gamma, beta)
+    N, S, Cc = _nsc(x)
+    y = new_act(*x.shape, like=x)
+    mr = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
+    L.check(L.load().rehr_instnorm_act_fwd_f32(_ptr(x), Cc, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(y), Cc,
+                                               _ptr(mr), N, S, Cc, eps, act, slope, _stream()),
+            "rehr_instnorm_act_fwd_f32")
+    return y, mr
+
+
+def instnorm_act_bwd(dy, x, mr, gamma, beta, act, slope):
+    _chk_dev(dy, x, mr, gamma, beta)
+    N, S, Cc = _nsc(x)
+    dx = new_act(*x.shape, like=x)
+    dg = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    red = torch.zeros((N, Cc, 2), dtype=torch.float64, device=x.device)
+    L.check(L.load().rehr_instnorm_act_bwd_f32(_ptr(dy), Cc, _ptr(x), Cc, _ptr(mr), _ptr(gamma), _ptr(beta),
+                                               _ptr(dx), Cc, _ptr(dg), _ptr(db), _ptr(red), N, S, Cc, act, slope,
+                                               _stream()), "rehr_instnorm_act_bwd_f32")
+    return dx, dg, db
+
+
+def upsample_depth_fwd(x, Do):
+    _chk_dev(x)
+    N, Cc, Di, H, W = x.shape
+    y = new_act(N, Cc, Do, H, W, like=x)
+    L.check(L.load().rehr_upsample_depth_fwd_f32(_ptr(x), _ptr(y), N, Di, Do, H * W, Cc, _stream()),
+            "rehr_upsample_depth_fwd_f32")
+    return y
+
+
+def upsample_depth_bwd(dy, Di):
+    _chk_dev(dy)
+    N, Cc, Do, H, W = dy.shape
+    dx = new_act(N, Cc, Di, H, W, like=dy)
+    L.check(L.load().rehr_upsample_depth_bwd_f32(_ptr(dy), _ptr(dx), N, Di, Do, H * W, Cc, _stream()),
+            "rehr_upsample_depth_bwd_f32")
+    return dx
+
+
+def act_fwd(x, act, slope):
+    _chk_dev(x)
+    y = torch.empty_like(x)
+    L.check(L.load().rehr_act_fwd_f32(_ptr(x), _ptr(y), x.numel(), act, slope, _stream()), "rehr_act_fwd_f32")
+    return y
+
+
+def act_bwd(dy, y, act, slope):
+    _chk_dev(dy, y)
+    dx = torch.empty_like(y)
+    L.check(L.load().rehr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), act, slope, _stream()),
+            "rehr_act_bwd_f32")
+    return dx
+
+
+def channel_sum(x):
+    _chk_dev(x)
+    N, S, Cc = _nsc(x)
+    out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((Cc,), dtype=torch.float64, device=x.device)
+    L.check(L.load().rehr_channel_sum_f32(_ptr(x), Cc, N * S, Cc, _ptr(out), 0, _ptr(scratch), _stream()),
+            "rehr_channel_sum_f32")
+    return out

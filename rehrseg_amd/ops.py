@@ -1,0 +1,374 @@
+"""Host-side operators of the hot path: geometry (stride phases, tap tables,
+lattice tiles), weight packing and the autograd glue around the C-ABI kernels.
+
+What each operator replaces in the reference (all torch.nn eager ops there):
+  fused_conv3d(mode="plain")  Conv3d(+ReLU)            models/FLAVR/resnet_3D.py:19-33,122-133,196-200
+  fused_conv3d(se=...)        Conv3d/ConvTranspose3d -> SEGating (-> +residual) -> ReLU/LeakyReLU
+                                                       resnet_3D.py:100-116,140-151; FLAVR_arch.py:40-88,188-200
+  fused_conv3d(inorm=...)     Conv3d -> InstanceNorm3d -> LeakyReLU (nnU-Net ConvDropoutNormReLU,
+                                                       dynamic_network_architectures==0.3.1; seg_model.py:174-191)
+  fused_conv3d(transposed)    ConvTranspose3d          FLAVR_arch.py:50; UNetDecoder.transpconvs (seg_model.py:35)
+  upsample_depth              F.interpolate(scale=(u,1,1), trilinear, align_corners=True)  seg_model.py:204
+
+PyTorch supplies autograd bookkeeping, device memory and the stream; every
+arithmetic step is a kernel of librehrseg_hip.so.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip_backend
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+_backend = hip_backend
+
+
+def get_backend():
+    return _backend
+
+
+def set_backend(b):
+    """Tests swap in a CPU emulator of the C-ABI to exercise this host logic
+    without a GPU; the product never calls this."""
+    global _backend
+    old = _backend
+    _backend = b
+    return old
+
+
+# ----------------------------------------------------------------------------- layout
+def to_cl(x: torch.Tensor) -> torch.Tensor:
+    """Logical (N,C,D,H,W) tensor whose memory is NDHWC-dense, fp32."""
+    if x.dim() != 5:
+        raise ValueError(f"expected a 5-D (N,C,D,H,W) tensor, got {tuple(x.shape)}")
+    if x.dtype not in (torch.float32, torch.float64):  # float64 only ever reaches the CPU emulator in tests
+        x = x.float()
+    if x.permute(0, 2, 3, 4, 1).is_contiguous():
+        return x
+    return x.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+
+
+def _triple(v):
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(a) for a in v)
+    if len(v) != 3:
+        raise ValueError(f"expected 3 values, got {v}")
+    return v
+
+
+# ----------------------------------------------------------------------------- geometry
+def conv_out_dim(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+def phase_taps(K, s, p, phase):
+    """Taps of a stride-``s`` / kernel-``K`` / pad-``p`` convolution that touch the
+    positions ``== phase (mod s)`` of its un-strided side (input gradient of a
+    Conv3d, output of a ConvTranspose3d).  Position ``s*q + phase`` reads the
+    strided side at ``q + off0 - j`` with weight index ``k0 + s*j``."""
+    k0 = (phase + p) % s
+    if k0 >= K:
+        return None
+    count = (K - k0 + s - 1) // s
+    off0 = (phase + p - k0) // s
+    return (count, off0, -1, k0, s)
+
+
+def full_taps(K):
+    return (K, 0, 1, 0, 1)
+
+
+def choose_tile(lattice):
+    """128-voxel lattice tile with the least padding (ties: smaller halo, wider w).
+    Returns (0,0,0) = runs of 128 flattened points when bricks waste > 10 % more."""
+    Ld, Lh, Lw = lattice
+    best = None
+    for td in (1, 2, 4, 8, 16, 32, 64, 128):
+        for th in (1, 2, 4, 8, 16, 32, 64, 128):
+            if 128 % (td * th):
+                continue
+            tw = 128 // (td * th)
+            vol = (-(-Ld // td) * td) * (-(-Lh // th) * th) * (-(-Lw // tw) * tw)
+            halo = (td + 2) * (th + 2) * (tw + 2)
+            key = (vol, halo, -tw)
+            if best is None or key < best[0]:
+                best = (key, (td, th, tw))
+    lin = -(-(Ld * Lh * Lw) // 128) * 128
+    if best[0][0] > 1.10 * lin:
+        return (0, 0, 0)
+    return best[1]
+
+
+def pad_rows(a):
+    """Row padding of a packed weight panel (gather-GEMM N tiles are 32/64/128)."""
+    if a % 128 == 0 or a % 64 == 0:
+        return a
+    return -(-a // 32) * 32
+
+
+@dataclass(frozen=True)
+class ConvCfg:
+    stride: Tuple[int, int, int]
+    pad: Tuple[int, int, int]
+    transposed: bool = False
+    act: int = ACT_NONE
+    slope: float = 0.0
+    mode: str = "plain"  # plain | se | in
+    eps: float = 1e-5
+
+
+def _spatial(x):
+    return tuple(x.shape[2:])
+
+
+def _out_dims(in_dims, w_shape, cfg: ConvCfg):
+    K = tuple(w_shape[2:])
+    if cfg.transposed:
+        return tuple((i - 1) * s - 2 * p + k for i, k, s, p in zip(in_dims, K, cfg.stride, cfg.pad))
+    return tuple(conv_out_dim(i, k, s, p) for i, k, s, p in zip(in_dims, K, cfg.stride, cfg.pad))
+
+
+def _pack(w, dest_dim):
+    """wp[tap][dest rows (padded)][other dim]; dest_dim = which weight dim feeds the output channels."""
+    be = get_backend()
+    T = w.shape[2] * w.shape[3] * w.shape[4]
+    if dest_dim == 0:
+        A, B = w.shape[0], w.shape[1]
+        return be.pack_weights(w, A, pad_rows(A), B, T, False), pad_rows(A)
+    A, B = w.shape[1], w.shape[0]
+    return be.pack_weights(w, A, pad_rows(A), B, T, True), pad_rows(A)
+
+
+def _phased_gather(src1, src2, c1, Csrc, wp, Npad, dst, Cdst, K, stride, pad, bias, act, slope, stats, stats_mode):
+    """dst positions of every stride phase <- taps of src (Conv3d input gradient /
+    ConvTranspose3d forward)."""
+    be = get_backend()
+    src_dims, dst_dims = _spatial(src1), _spatial(dst)
+    for ph in itertools.product(*(range(s) for s in stride)):
+        taps = [phase_taps(K[a], stride[a], pad[a], ph[a]) for a in range(3)]
+        lattice = tuple((dst_dims[a] - ph[a] + stride[a] - 1) // stride[a] for a in range(3))
+        if min(lattice) <= 0:
+            continue
+        if any(t is None for t in taps):
+            continue  # no tap reaches this phase: dst keeps its zero fill
+        be.gather_gemm(src1, src2, c1, src_dims, Csrc, lattice, (1, 1, 1), (0, 0, 0), taps, K[1], K[2], wp, Npad,
+                       dst, dst_dims, Cdst, stride, ph, bias, act, slope, stats, stats_mode, choose_tile(lattice))
+
+
+def _has_empty_phase(K, stride, pad):
+    return any(phase_taps(K[a], stride[a], pad[a], ph) is None for a in range(3) for ph in range(stride[a]))
+
+
+def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
+    """Returns (y, stats).  x2 = second half of a virtual channel concat."""
+    be = get_backend()
+    N = x1.shape[0]
+    c1 = x1.shape[1]
+    Cin = c1 + (x2.shape[1] if x2 is not None else 0)
+    K = tuple(w.shape[2:])
+    in_dims = _spatial(x1)
+    out_dims = _out_dims(in_dims, w.shape, cfg)
+    Cout = w.shape[1] if cfg.transposed else w.shape[0]
+    if (w.shape[0] if cfg.transposed else w.shape[1]) != Cin:
+        raise ValueError(f"weight {tuple(w.shape)} does not match {Cin} input channels")
+    stats = torch.zeros((N, Cout, 2), dtype=torch.float64, device=x1.device) if stats_mode else None
+    if Cin <= 2:
+        if cfg.transposed or x2 is not None:
+            raise ValueError("thin-input path handles plain Conv3d only")
+        y = be.new_act(N, Cout, *out_dims, like=x1)
+        be.small_cin_fwd(x1, w, bias, y, cfg.stride, cfg.pad, act, slope, stats, stats_mode)
+        return y, stats
+    if cfg.transposed:
+        empty = _has_empty_phase(K, cfg.stride, cfg.pad)
+        if empty and bias is not None:
+            raise NotImplementedError("ConvTranspose3d with unreachable output phases and a bias")
+        y = be.new_act(N, Cout, *out_dims, like=x1, zero=empty)
+        wp, Npad = _pack(w, 1)
+        _phased_gather(x1, x2, c1, Cin, wp, Npad, y, Cout, K, cfg.stride, cfg.pad, bias, act, slope, stats,
+                       stats_mode)
+        return y, stats
+    y = be.new_act(N, Cout, *out_dims, like=x1)
+    wp, Npad = _pack(w, 0)
+    taps = [full_taps(k) for k in K]
+    be.gather_gemm(x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), taps, K[1], K[2],
+                   wp, Npad, y, out_dims, Cout, (1, 1, 1), (0, 0, 0), bias, act, slope, stats, stats_mode,
+                   choose_tile(out_dims))
+    return y, stats
+
+
+def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
+    """Input gradient(s) of conv_forward: (dx1, dx2)."""
+    be = get_backend()
+    N = dz.shape[0]
+    K = tuple(w.shape[2:])
+    Cz = dz.shape[1]
+    out = []
+    for (lo, cnt, need) in ((0, c1, need1), (c1, c2, need2)):
+        if cnt == 0 or not need:
+            out.append(None)
+            continue
+        if cfg.transposed:
+            # dX of ConvTranspose3d = strided Conv3d of dY with w[ci][co] (dest rows = dim 0)
+            wpart = w if (lo == 0 and cnt == w.shape[0]) else w[lo:lo + cnt].contiguous()
+            wp, Npad = _pack(wpart, 0)
+            dx = be.new_act(N, cnt, *in_dims, like=dz)
+            taps = [full_taps(k) for k in K]
+            be.gather_gemm(dz, None, Cz, _spatial(dz), Cz, in_dims, cfg.stride, tuple(-p for p in cfg.pad), taps,
+                           K[1], K[2], wp, Npad, dx, in_dims, cnt, (1, 1, 1), (0, 0, 0), None, ACT_NONE, 0.0, None,
+                           0, choose_tile(in_dims))
+        else:
+            wpart = w if (lo == 0 and cnt == w.shape[1]) else w[:, lo:lo + cnt].contiguous()
+            wp, Npad = _pack(wpart, 1)
+            dx = be.new_act(N, cnt, *in_dims, like=dz, zero=_has_empty_phase(K, cfg.stride, cfg.pad))
+            _phased_gather(dz, None, Cz, Cz, wp, Npad, dx, cnt, K, cfg.stride, cfg.pad, None, ACT_NONE, 0.0, None, 0)
+        out.append(dx)
+    return out[0], out[1]
+
+
+def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias):
+    """(dw, db) in the torch parameter layout of ``w``."""
+    be = get_backend()
+    N = x1.shape[0]
+    K = tuple(w.shape[2:])
+    T = K[0] * K[1] * K[2]
+    c1 = x1.shape[1]
+    Cin = c1 + (x2.shape[1] if x2 is not None else 0)
+    if Cin <= 2:
+        return be.small_cin_wgrad(x1, w, dz, cfg.stride, cfg.pad, want_bias)
+    dw = torch.empty(tuple(w.shape), dtype=w.dtype, device=w.device)
+    db = None
+    taps = [full_taps(k) for k in K]
+    b = tuple(-p for p in cfg.pad)
+    if cfg.transposed:
+        # lattice = input x (rows of w), gathered = dY (cols of w)
+        Cout = w.shape[1]
+        lo = 0
+        for xs in (x1, x2):
+            if xs is None:
+                continue
+            cnt = xs.shape[1]
+            be.wgrad(xs, cnt, dz, Cout, N, _spatial(xs), _spatial(dz), cfg.stride, b, taps, K[1], K[2], dw,
+                     lo * Cout * T, (Cout * T, T, 1), False, None)
+            lo += cnt
+        if want_bias:
+            db = be.channel_sum(dz)
+    else:
+        Cout = w.shape[0]
+        db = torch.empty((Cout,), dtype=w.dtype, device=w.device) if want_bias else None
+        lo = 0
+        first = True
+        for xs in (x1, x2):
+            if xs is None:
+                continue
+            cnt = xs.shape[1]
+            be.wgrad(dz, Cout, xs, cnt, N, _spatial(dz), _spatial(xs), cfg.stride, b, taps, K[1], K[2], dw, lo * T,
+                     (Cin * T, T, 1), False, db if first else None)
+            first = False
+            lo += cnt
+    return dw, db
+
+
+# ----------------------------------------------------------------------------- autograd
+class _FusedConv(torch.autograd.Function):
+    """conv / transposed conv, optionally followed by SEGating(+residual)+act or
+    InstanceNorm+act, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b, p1, p2, res, cfg: ConvCfg):
+        be = get_backend()
+        x1 = to_cl(x1)
+        x2 = to_cl(x2) if x2 is not None else None
+        res = to_cl(res) if res is not None else None
+        N = x1.shape[0]
+        if cfg.mode == "plain":
+            y, _ = conv_forward(x1, x2, w, b, cfg, cfg.act, cfg.slope, 0)
+            y0 = gate = mean = mr = None
+        elif cfg.mode == "se":
+            y0, stats = conv_forward(x1, x2, w, b, cfg, ACT_NONE, 0.0, 1)
+            Cc = y0.shape[1]
+            S = y0.shape[2] * y0.shape[3] * y0.shape[4]
+            gate, mean = be.se_gate_fwd(stats, p1.reshape(Cc, Cc), p2, N, Cc, S)
+            y = be.scale_res_act_fwd(y0, gate, res, cfg.act, cfg.slope)
+            mr = None
+        elif cfg.mode == "in":
+            y0, stats = conv_forward(x1, x2, w, b, cfg, ACT_NONE, 0.0, 2)
+            y, mr = be.instnorm_act_fwd(y0, stats, p1, p2, cfg.eps, cfg.act, cfg.slope)
+            gate = mean = None
+        else:
+            raise ValueError(cfg.mode)
+        ctx.cfg = cfg
+        ctx.has = (x2 is not None, b is not None, res is not None)
+        ctx.save_for_backward(x1, x2, w, p1, p2, y0, y, gate, mean, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = get_backend()
+        cfg = ctx.cfg
+        x1, x2, w, p1, p2, y0, y, gate, mean, mr = ctx.saved_tensors
+        has_x2, has_b, has_res = ctx.has
+        dy = to_cl(dy)
+        dp1 = dp2 = dres = None
+        if cfg.mode == "plain":
+            dz = be.act_bwd(dy, y, cfg.act, cfg.slope) if cfg.act != ACT_NONE else dy
+        elif cfg.mode == "se":
+            Cc = y0.shape[1]
+            S = y0.shape[2] * y0.shape[3] * y0.shape[4]
+            dz, dres, dgate = be.scale_res_act_bwd(dy, y, y0, gate, has_res, cfg.act, cfg.slope)
+            dp1, dp2, k = be.se_gate_bwd(dgate, gate, mean, p1.reshape(Cc, Cc), S)
+            dp1 = dp1.reshape(p1.shape)
+            be.add_channel_const(dz, k)
+        else:
+            dz, dp1, dp2 = be.instnorm_act_bwd(dy, y0, mr, p1, p2, cfg.act, cfg.slope)
+        need = ctx.needs_input_grad
+        c1 = x1.shape[1]
+        c2 = x2.shape[1] if has_x2 else 0
+        dx1 = dx2 = None
+        if need[0] or (has_x2 and need[1]):
+            dx1, dx2 = conv_dgrad(dz, w, _spatial(x1), c1, c2, cfg, need[0], has_x2 and need[1])
+        dw = db = None
+        if need[2] or (has_b and need[3]):
+            dw, db = conv_wgrad(dz, x1, x2, w, cfg, has_b)
+        return dx1, dx2, dw, db, dp1, dp2, dres, None
+
+
+def fused_conv3d(x, w, b=None, stride=1, padding=0, *, x2=None, transposed=False, act=ACT_NONE, slope=0.0,
+                 se=None, res=None, inorm=None, eps=1e-5):
+    """Conv3d / ConvTranspose3d with the fused tails of the hot path.
+
+    x2     second tensor of a virtual channel concat (input = cat([x, x2], 1))
+    se     (attn_weight (C,C,1,1,1), attn_bias (C,)): y = act(conv * gate + res)
+    inorm  (gamma, beta): y = act(InstanceNorm(conv))
+    """
+    if se is not None and inorm is not None:
+        raise ValueError("se and inorm are exclusive")
+    mode = "se" if se is not None else ("in" if inorm is not None else "plain")
+    if res is not None and mode != "se":
+        raise ValueError("res is only fused behind SEGating")
+    cfg = ConvCfg(_triple(stride), _triple(padding), bool(transposed), int(act), float(slope), mode, float(eps))
+    p1, p2 = (se if se is not None else (inorm if inorm is not None else (None, None)))
+    return _FusedConv.apply(x, x2, w, b, p1, p2, res, cfg)
+
+
+class _UpsampleDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Do):
+        x = to_cl(x)
+        ctx.Di = x.shape[2]
+        return get_backend().upsample_depth_fwd(x, Do)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return get_backend().upsample_depth_bwd(to_cl(dy), ctx.Di), None
+
+
+def upsample_depth(x, scale):
+    """Linear interpolation along depth only, align_corners=True (seg_model.py:204)."""
+    Do = int(x.shape[2] * scale)
+    return _UpsampleDepth.apply(x, Do)

@@ -1,0 +1,218 @@
+"""CPU emulation of the C-ABI entry points (include/rehrseg_hip.h), TEST ONLY.
+
+It restates the *contract* of every entry point -- the descriptor semantics the
+HIP kernels implement -- in plain torch on the CPU, so that the host logic in
+rehrseg_amd/ops.py (stride phases, tap tables, packing, virtual concat, SE /
+InstanceNorm backward algebra) can be checked against torch.nn.functional without
+a GPU.  Nothing under rehrseg_amd/ imports this file.
+"""
+import torch
+
+name = "emu"
+
+
+def _act(v, act, slope):
+    if act == 1:
+        return torch.relu(v)
+    if act == 2:
+        return torch.where(v > 0, v, v * slope)
+    return v
+
+
+def _act_grad(y, act, slope):
+    if act == 1:
+        return (y > 0).to(y.dtype)
+    if act == 2:
+        return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+    return torch.ones_like(y)
+
+
+def new_act(N, Cc, D, H, W, like, zero=False):
+    t = torch.empty((N, Cc, D, H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last_3d)
+    return t.zero_() if zero else t.fill_(float("nan"))  # unwritten voxels must be noticed
+
+
+def pack_weights(w, A, Apad, B, T, transpose):
+    w = w.contiguous()
+    out = torch.zeros((T, Apad, B), dtype=w.dtype)
+    if transpose:  # in[b][a][t]
+        out[:, :A, :] = w.reshape(B, A, T).permute(2, 1, 0)
+    else:          # in[a][b][t]
+        out[:, :A, :] = w.reshape(A, B, T).permute(2, 0, 1)
+    return out
+
+
+def _axis(L, s, b, off, size):
+    idx = torch.arange(L) * s + b + off
+    ok = (idx >= 0) & (idx < size)
+    return idx.clamp(0, size - 1), ok
+
+
+def _gather(X, lattice, s, b, off, dims):
+    """X: (N,C,D,H,W) -> (N,C,Ld,Lh,Lw) of X[o*s+b+off], zero outside."""
+    (idd, okd), (idh, okh), (idw, okw) = (_axis(lattice[a], s[a], b[a], off[a], dims[a]) for a in range(3))
+    g = X[:, :, idd][:, :, :, idh][:, :, :, :, idw]
+    m = (okd[:, None, None] & okh[None, :, None] & okw[None, None, :]).to(X.dtype)
+    return g * m
+
+
+def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
+                os_, ob, bias, act, slope, stats, stats_mode, tile):
+    assert Cin % 32 == 0 and c1 % 32 == 0 and Npad % 32 == 0 and wp.shape[1] == Npad and wp.shape[2] == Cin
+    assert tile == (0, 0, 0) or tile[0] * tile[1] * tile[2] == 128
+    assert tuple(x1.shape[2:]) == tuple(src_dims) and tuple(y.shape[2:]) == tuple(y_dims)
+    X = torch.cat([x1, x2], 1) if x2 is not None else x1
+    assert X.shape[1] == Cin
+    N = X.shape[0]
+    acc = torch.zeros((N, Cout) + tuple(lattice), dtype=X.dtype)
+    (cd, od0, ods, kd0, kds), (ch, oh0, ohs, kh0, khs), (cw, ow0, ows, kw0, kws) = taps
+    for jd in range(cd):
+        for jh in range(ch):
+            for jw in range(cw):
+                off = (od0 + ods * jd, oh0 + ohs * jh, ow0 + ows * jw)
+                wt = ((kd0 + kds * jd) * KH + (kh0 + khs * jh)) * KW + (kw0 + kws * jw)
+                g = _gather(X, lattice, s, b, off, src_dims)
+                acc += torch.einsum("ncdhw,oc->nodhw", g, wp[wt, :Cout, :])
+    if bias is not None:
+        acc += bias.view(1, -1, 1, 1, 1)
+    acc = _act(acc, act, slope)
+    for a in range(3):
+        assert ob[a] >= 0 and (lattice[a] - 1) * os_[a] + ob[a] < y_dims[a]
+    y[:, :, ob[0]:ob[0] + (lattice[0] - 1) * os_[0] + 1:os_[0],
+      ob[1]:ob[1] + (lattice[1] - 1) * os_[1] + 1:os_[1],
+      ob[2]:ob[2] + (lattice[2] - 1) * os_[2] + 1:os_[2]] = acc
+    if stats_mode:
+        stats[:, :, 0] += acc.double().sum((2, 3, 4))
+        if stats_mode == 2:
+            stats[:, :, 1] += (acc.double() ** 2).sum((2, 3, 4))
+
+
+def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):
+    assert Ca % 32 == 0 and Cg % 32 == 0 and tuple(l.shape[2:]) == tuple(lattice)
+    flat = dst.view(-1)
+    (cd, od0, ods, kd0, kds), (ch, oh0, ohs, kh0, khs), (cw, ow0, ows, kw0, kws) = taps
+    sa, sc, st = dst_strides
+    ia = torch.arange(Ca)[:, None] * sa
+    ic = torch.arange(Cg)[None, :] * sc
+    for jd in range(cd):
+        for jh in range(ch):
+            for jw in range(cw):
+                off = (od0 + ods * jd, oh0 + ohs * jh, ow0 + ows * jw)
+                wt = ((kd0 + kds * jd) * KH + (kh0 + khs * jh)) * KW + (kw0 + kws * jw)
+                gg = _gather(g, lattice, s, b, off, g_dims)
+                val = torch.einsum("nadhw,ncdhw->ac", l, gg)
+                idx = (dst_off + ia + ic + wt * st).reshape(-1)
+                if accumulate:
+                    flat[idx] += val.reshape(-1)
+                else:
+                    flat[idx] = val.reshape(-1)
+    if dbias is not None:
+        v = l.sum((0, 2, 3, 4))
+        dbias.copy_(dbias + v if accumulate else v)
+
+
+def small_cin_fwd(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
+    assert x.shape[1] <= 2 and w.shape[0] in (16, 32, 64)
+    v = torch.nn.functional.conv3d(x, w, bias, stride, pad)
+    v = _act(v, act, slope)
+    y.copy_(v)
+    if stats_mode:
+        stats[:, :, 0] += v.double().sum((2, 3, 4))
+        if stats_mode == 2:
+            stats[:, :, 1] += (v.double() ** 2).sum((2, 3, 4))
+
+
+def small_cin_wgrad(x, w, dy, stride, pad, want_bias):
+    dw = torch.nn.grad.conv3d_weight(x, w.shape, dy, stride, pad)
+    return dw, (dy.sum((0, 2, 3, 4)) if want_bias else None)
+
+
+def se_gate_fwd(stats, w, b, N, Cc, S):
+    mean = (stats[:, :, 0] / S).to(w.dtype)
+    gate = torch.sigmoid(mean @ w.t() + b)
+    return gate, mean
+
+
+def scale_res_act_fwd(x, gate, res, act, slope):
+    v = x * gate[:, :, None, None, None]
+    if res is not None:
+        v = v + res
+    return _act(v, act, slope).contiguous(memory_format=torch.channels_last_3d)
+
+
+def scale_res_act_bwd(dy, y, x, gate, want_dres, act, slope):
+    dz = dy * _act_grad(y, act, slope)
+    dx = (dz * gate[:, :, None, None, None]).contiguous(memory_format=torch.channels_last_3d)
+    dgate = (dz * x).double().sum((2, 3, 4))
+    return dx, (dz.contiguous(memory_format=torch.channels_last_3d) if want_dres else None), dgate
+
+
+def se_gate_bwd(dgate, gate, mean, w, S):
+    ds = dgate.to(gate.dtype) * gate * (1 - gate)
+    dw = ds.t() @ mean
+    db = ds.sum(0)
+    k = (ds @ w) / S
+    return dw, db, k
+
+
+def add_channel_const(x, k):
+    x += k[:, :, None, None, None]
+
+
+def instnorm_act_fwd(x, stats, gamma, beta, eps, act, slope):
+    N, Cc = x.shape[:2]
+    S = x[0, 0].numel()
+    mean = stats[:, :, 0] / S
+    var = (stats[:, :, 1] / S - mean * mean).clamp_min(0)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    mr = torch.stack([mean, rstd], -1).to(x.dtype)
+    xh = (x - mr[:, :, 0, None, None, None]) * mr[:, :, 1, None, None, None]
+    y = _act(xh * gamma.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1), act, slope)
+    return y.contiguous(memory_format=torch.channels_last_3d), mr
+
+
+def instnorm_act_bwd(dy, x, mr, gamma, beta, act, slope):
+    xh = (x - mr[:, :, 0, None, None, None]) * mr[:, :, 1, None, None, None]
+    z = xh * gamma.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)
+    dz = dy * _act_grad(z, act, slope)
+    dgamma = (dz * xh).sum((0, 2, 3, 4))
+    dbeta = dz.sum((0, 2, 3, 4))
+    m1 = dz.mean((2, 3, 4), keepdim=True)
+    m2 = (dz * xh).mean((2, 3, 4), keepdim=True)
+    dx = mr[:, :, 1, None, None, None] * gamma.view(1, -1, 1, 1, 1) * (dz - m1 - xh * m2)
+    return dx.contiguous(memory_format=torch.channels_last_3d), dgamma, dbeta
+
+
+def _depth_w(Di, Do, dtype):
+    Wm = torch.zeros((Do, Di), dtype=dtype)
+    scale = (Di - 1) / (Do - 1) if Do > 1 else 0.0
+    for od in range(Do):
+        src = torch.tensor(scale, dtype=torch.float32) * od
+        i0 = min(int(src), Di - 1)
+        i1 = min(i0 + 1, Di - 1)
+        w1 = float(src - i0)
+        Wm[od, i0] += 1 - w1
+        Wm[od, i1] += w1
+    return Wm
+
+
+def upsample_depth_fwd(x, Do):
+    Wm = _depth_w(x.shape[2], Do, x.dtype)
+    return torch.einsum("od,ncdhw->ncohw", Wm, x).contiguous(memory_format=torch.channels_last_3d)
+
+
+def upsample_depth_bwd(dy, Di):
+    Wm = _depth_w(Di, dy.shape[2], dy.dtype)
+    return torch.einsum("od,ncohw->ncdhw", Wm, dy).contiguous(memory_format=torch.channels_last_3d)
+
+
+def act_fwd(x, act, slope):
+    return _act(x, act, slope)
+
+
+def act_bwd(dy, y, act, slope):
+    return dy * _act_grad(y, act, slope)
+
+
+def channel_sum(x):
+    return x.sum((0, 2, 3, 4))

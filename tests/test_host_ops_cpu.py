@@ -1,0 +1,184 @@
+"""Host logic of rehrseg_amd.ops (phases, taps, packing, virtual concat, fused
+tails) against torch.nn.functional, with the C-ABI emulated on the CPU in fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rehrseg_amd import ops
+
+torch.manual_seed(0)
+DT = torch.float64
+
+
+def _rand(*s):
+    return torch.randn(*s, dtype=DT)
+
+
+def _grads(out, inputs):
+    g = torch.randn_like(out)
+    return torch.autograd.grad(out, inputs, g, allow_unused=True), g
+
+
+def _cmp(a, b, tol=1e-9):
+    assert a.shape == b.shape
+    assert torch.allclose(a, b, rtol=tol, atol=tol), float((a - b).abs().max())
+
+
+CONVS = [
+    # Cin, Cout, K, stride, pad, dims
+    (32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (3, 6, 7)),
+    (64, 32, (3, 3, 3), (1, 2, 2), (1, 1, 1), (4, 9, 8)),      # layer2/3 first conv
+    (32, 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 8, 7)),      # downsample projection
+    (32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 5, 5)),      # anisotropic nnU-Net kernel
+    (32, 96, (3, 3, 3), (2, 2, 2), (1, 1, 1), (5, 6, 7)),      # nnU-Net strided stage, odd extents
+    (32, 32, (5, 5, 5), (1, 1, 1), (2, 2, 2), (4, 5, 6)),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", CONVS)
+def test_conv3d_fwd_bwd(emu, Cin, Cout, K, stride, pad, dims):
+    x = _rand(2, Cin, *dims).requires_grad_()
+    w = _rand(Cout, Cin, *K).requires_grad_()
+    b = _rand(Cout).requires_grad_()
+    y = ops.fused_conv3d(x, w, b, stride, pad, act=ops.ACT_LRELU, slope=0.2)
+    ref = F.leaky_relu(F.conv3d(x, w, b, stride, pad), 0.2)
+    _cmp(y, ref)
+    g = torch.randn_like(ref)
+    got = torch.autograd.grad(y, (x, w, b), g)
+    exp = torch.autograd.grad(ref, (x, w, b), g)
+    for a, e in zip(got, exp):
+        _cmp(a, e)
+
+
+TCONVS = [
+    (64, 32, (3, 4, 4), (1, 2, 2), (1, 1, 1), (3, 5, 6)),   # FLAVR upConv3D
+    (64, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (3, 4, 5)),   # nnU-Net transpconv kernel = stride
+    (32, 32, (1, 2, 2), (1, 2, 2), (0, 0, 0), (2, 3, 3)),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", TCONVS)
+def test_conv_transpose3d_fwd_bwd(emu, Cin, Cout, K, stride, pad, dims):
+    x = _rand(2, Cin, *dims).requires_grad_()
+    w = _rand(Cin, Cout, *K).requires_grad_()
+    b = _rand(Cout).requires_grad_()
+    y = ops.fused_conv3d(x, w, b, stride, pad, transposed=True)
+    ref = F.conv_transpose3d(x, w, b, stride, pad)
+    _cmp(y, ref)
+    g = torch.randn_like(ref)
+    got = torch.autograd.grad(y, (x, w, b), g)
+    exp = torch.autograd.grad(ref, (x, w, b), g)
+    for a, e in zip(got, exp):
+        _cmp(a, e)
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_virtual_concat(emu, transposed):
+    x1 = _rand(1, 32, 3, 4, 5).requires_grad_()
+    x2 = _rand(1, 64, 3, 4, 5).requires_grad_()
+    if transposed:
+        w = _rand(96, 32, 3, 4, 4).requires_grad_()
+        args = ((1, 2, 2), (1, 1, 1))
+        ref = F.conv_transpose3d(torch.cat([x1, x2], 1), w, None, *args)
+    else:
+        w = _rand(64, 96, 3, 3, 3).requires_grad_()
+        args = ((1, 1, 1), (1, 1, 1))
+        ref = F.conv3d(torch.cat([x1, x2], 1), w, None, *args)
+    y = ops.fused_conv3d(x1, w, None, *args, x2=x2, transposed=transposed)
+    _cmp(y, ref)
+    g = torch.randn_like(ref)
+    got = torch.autograd.grad(y, (x1, x2, w), g)
+    exp = torch.autograd.grad(ref, (x1, x2, w), g)
+    for a, e in zip(got, exp):
+        _cmp(a, e)
+
+
+def _se_ref(v, aw, ab):
+    m = v.mean((2, 3, 4), keepdim=True)
+    return v * torch.sigmoid(F.conv3d(m, aw, ab))
+
+
+@pytest.mark.parametrize("with_res,act", [(True, ops.ACT_RELU), (False, ops.ACT_LRELU)])
+def test_conv_se_block(emu, with_res, act):
+    x = _rand(2, 32, 3, 5, 4).requires_grad_()
+    w = _rand(32, 32, 3, 3, 3).requires_grad_()
+    b = _rand(32).requires_grad_()
+    aw = _rand(32, 32, 1, 1, 1).requires_grad_()
+    ab = _rand(32).requires_grad_()
+    res = _rand(2, 32, 3, 5, 4).requires_grad_() if with_res else None
+    y = ops.fused_conv3d(x, w, b, 1, 1, se=(aw, ab), res=res, act=act, slope=0.2)
+    v = _se_ref(F.conv3d(x, w, b, 1, 1), aw, ab)
+    if with_res:
+        v = v + res
+    ref = torch.relu(v) if act == ops.ACT_RELU else F.leaky_relu(v, 0.2)
+    _cmp(y, ref)
+    ins = [x, w, b, aw, ab] + ([res] if with_res else [])
+    g = torch.randn_like(ref)
+    got = torch.autograd.grad(y, ins, g)
+    exp = torch.autograd.grad(ref, ins, g)
+    for a, e in zip(got, exp):
+        _cmp(a, e, 1e-8)
+
+
+def test_conv_instnorm_lrelu_block(emu):
+    x = _rand(2, 32, 4, 5, 6).requires_grad_()
+    w = _rand(64, 32, 3, 3, 3).requires_grad_()
+    b = _rand(64).requires_grad_()
+    ga = _rand(64).requires_grad_()
+    be = _rand(64).requires_grad_()
+    y = ops.fused_conv3d(x, w, b, (1, 2, 2), 1, inorm=(ga, be), eps=1e-5, act=ops.ACT_LRELU, slope=0.01)
+    ref = F.leaky_relu(F.instance_norm(F.conv3d(x, w, b, (1, 2, 2), 1), weight=ga, bias=be, eps=1e-5), 0.01)
+    _cmp(y, ref, 1e-8)
+    g = torch.randn_like(ref)
+    got = torch.autograd.grad(y, (x, w, b, ga, be), g)
+    exp = torch.autograd.grad(ref, (x, w, b, ga, be), g)
+    for a, e in zip(got, exp):
+        _cmp(a, e, 1e-7)
+
+
+def test_thin_input_conv(emu):
+    x = _rand(2, 1, 4, 10, 9)
+    w = _rand(64, 1, 3, 7, 7).requires_grad_()
+    b = _rand(64).requires_grad_()
+    y = ops.fused_conv3d(x, w, b, (1, 2, 2), (1, 3, 3), act=ops.ACT_RELU)
+    ref = torch.relu(F.conv3d(x, w, b, (1, 2, 2), (1, 3, 3)))
+    _cmp(y, ref)
+    g = torch.randn_like(ref)
+    for a, e in zip(torch.autograd.grad(y, (w, b), g), torch.autograd.grad(ref, (w, b), g)):
+        _cmp(a, e)
+
+
+@pytest.mark.parametrize("Di,scale", [(5, 4), (7, 2), (1, 3)])
+def test_upsample_depth(emu, Di, scale):
+    x = _rand(2, 32, Di, 3, 4).requires_grad_()
+    y = ops.upsample_depth(x, scale)
+    ref = F.interpolate(x, scale_factor=(scale, 1, 1), mode="trilinear", align_corners=True)
+    _cmp(y, ref, 1e-6)  # source index is computed in fp32, like ATen does for float tensors
+    g = torch.randn_like(ref)
+    _cmp(torch.autograd.grad(y, x, g)[0], torch.autograd.grad(ref, x, g)[0], 1e-6)
+
+
+def test_choose_tile():
+    assert ops.choose_tile((128, 64, 64))[0] * ops.choose_tile((128, 64, 64))[1] * ops.choose_tile((128, 64, 64))[2] == 128
+    assert ops.choose_tile((4, 12, 12)) == (0, 0, 0)
+    td, th, tw = ops.choose_tile((1, 128, 128))
+    assert td == 1 and th * tw == 128
+
+
+def test_phase_taps_cover_every_tap_once():
+    for K, s, p in [(3, 2, 1), (4, 2, 1), (1, 2, 0), (2, 2, 0), (3, 1, 1), (5, 3, 2)]:
+        seen = []
+        for ph in range(s):
+            t = ops.phase_taps(K, s, p, ph)
+            if t is None:
+                continue
+            count, off0, offs, k0, ks = t
+            for j in range(count):
+                k = k0 + ks * j
+                assert 0 <= k < K
+                # position s*q+ph reads strided index q+off0+offs*j: check o*s - p + k == s*q+ph
+                q = 3
+                o = q + off0 + offs * j
+                assert o * s - p + k == s * q + ph
+                seen.append(k)
+        assert sorted(seen) == list(range(K))

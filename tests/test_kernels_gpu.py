@@ -1,0 +1,168 @@
+"""Parity of the HIP kernels (through the C-ABI) against torch.nn.functional on
+the CPU in fp64.  Tolerance: 1e-4 of the reference's max magnitude for forward
+values and gradients (fp32 MFMA is an exact-fp32 fma chain; only the summation
+order differs from ATen/oneDNN)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rehrseg_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, tol=TOL):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = float(ref.abs().max()) + 1e-30
+    err = float((got - ref).abs().max()) / scale
+    assert err <= tol, f"rel err {err:.3e} > {tol}"
+
+
+def _mk(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+def _run(fn_gpu, fn_ref, tensors, grad_mask):
+    dev = _dev()
+    gin = [t.to(dev).requires_grad_(m) for t, m in zip(tensors, grad_mask)]
+    rin = [t.double().requires_grad_(m) for t, m in zip(tensors, grad_mask)]
+    y = fn_gpu(*gin)
+    ref = fn_ref(*rin)
+    _close(y, ref)
+    g = _mk(*ref.shape, seed=99)
+    gg = torch.autograd.grad(y, [t for t, m in zip(gin, grad_mask) if m], g.to(dev))
+    rg = torch.autograd.grad(ref, [t for t, m in zip(rin, grad_mask) if m], g.double())
+    for a, e in zip(gg, rg):
+        _close(a, e)
+
+
+CONVS = [
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 5, 12, 20)),
+    (64, 128, (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 4, 18, 16)),
+    (64, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 3, 16, 14)),
+    (128, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 8, 8)),
+    (32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 9, 11)),
+    (32, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 9, 10, 11)),
+    (320, 320, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 4, 4)),
+    (32, 32, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 6, 7, 8)),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", CONVS)
+def test_conv3d(Cin, Cout, K, stride, pad, dims):
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=1)
+    w = _mk(Cout, Cin, *K, seed=2) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=3)
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, stride, pad, act=ops.ACT_LRELU, slope=0.2),
+         lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, stride, pad), 0.2), [x, w, b], [True, True, True])
+
+
+TCONVS = [
+    (128, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (1, 4, 9, 10)),
+    (64, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 3, 5, 6)),
+    (320, 320, (1, 2, 2), (1, 2, 2), (0, 0, 0), (1, 4, 4, 4)),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", TCONVS)
+def test_conv_transpose3d(Cin, Cout, K, stride, pad, dims):
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=4)
+    w = _mk(Cin, Cout, *K, seed=5) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=6)
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, stride, pad, transposed=True),
+         lambda x, w, b: F.conv_transpose3d(x, w, b, stride, pad), [x, w, b], [True, True, True])
+
+
+def test_virtual_concat_conv():
+    x1, x2 = _mk(1, 64, 4, 10, 12, seed=7), _mk(1, 128, 4, 10, 12, seed=8)
+    w = _mk(64, 192, 3, 3, 3, seed=9) / 72.0
+    _run(lambda a, b, w: ops.fused_conv3d(a, w, None, 1, 1, x2=b),
+         lambda a, b, w: F.conv3d(torch.cat([a, b], 1), w, None, 1, 1), [x1, x2, w], [True, True, True])
+
+
+def test_virtual_concat_transposed():
+    x1, x2 = _mk(1, 64, 3, 6, 7, seed=10), _mk(1, 64, 3, 6, 7, seed=11)
+    w = _mk(128, 64, 3, 4, 4, seed=12) / 70.0
+    _run(lambda a, b, w: ops.fused_conv3d(a, w, None, (1, 2, 2), 1, x2=b, transposed=True),
+         lambda a, b, w: F.conv_transpose3d(torch.cat([a, b], 1), w, None, (1, 2, 2), 1), [x1, x2, w],
+         [True, True, True])
+
+
+def _se(v, aw, ab):
+    return v * torch.sigmoid(F.conv3d(v.mean((2, 3, 4), keepdim=True), aw, ab))
+
+
+@pytest.mark.parametrize("with_res", [True, False])
+def test_conv_se_block(with_res):
+    x = _mk(2, 64, 4, 9, 10, seed=13)
+    w = _mk(64, 64, 3, 3, 3, seed=14) / 41.0
+    b = _mk(64, seed=15)
+    aw = _mk(64, 64, 1, 1, 1, seed=16) / 8.0
+    ab = _mk(64, seed=17)
+    res = _mk(2, 64, 4, 9, 10, seed=18)
+    if with_res:
+        _run(lambda x, w, b, aw, ab, r: ops.fused_conv3d(x, w, b, 1, 1, se=(aw, ab), res=r, act=ops.ACT_RELU),
+             lambda x, w, b, aw, ab, r: torch.relu(_se(F.conv3d(x, w, b, 1, 1), aw, ab) + r),
+             [x, w, b, aw, ab, res], [True] * 6)
+    else:
+        _run(lambda x, w, b, aw, ab: ops.fused_conv3d(x, w, b, 1, 1, se=(aw, ab), act=ops.ACT_LRELU, slope=0.2),
+             lambda x, w, b, aw, ab: F.leaky_relu(_se(F.conv3d(x, w, b, 1, 1), aw, ab), 0.2),
+             [x, w, b, aw, ab], [True] * 5)
+
+
+def test_conv_instnorm_lrelu_block():
+    x = _mk(2, 32, 5, 9, 11, seed=19)
+    w = _mk(64, 32, 3, 3, 3, seed=20) / 29.0
+    b = _mk(64, seed=21)
+    ga = _mk(64, seed=22)
+    be = _mk(64, seed=23)
+    _run(lambda x, w, b, ga, be: ops.fused_conv3d(x, w, b, (1, 2, 2), 1, inorm=(ga, be), act=ops.ACT_LRELU,
+                                                   slope=0.01),
+         lambda x, w, b, ga, be: F.leaky_relu(
+             F.instance_norm(F.conv3d(x, w, b, (1, 2, 2), 1), weight=ga, bias=be, eps=1e-5), 0.01),
+         [x, w, b, ga, be], [True] * 5)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad", [(1, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
+                                                    (2, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
+                                                    (1, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+                                                    (1, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1))])
+def test_thin_input_conv(Cin, Cout, K, stride, pad):
+    x = _mk(2, Cin, 5, 17, 19, seed=24)
+    w = _mk(Cout, Cin, *K, seed=25) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=26)
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, stride, pad, act=ops.ACT_RELU),
+         lambda x, w, b: torch.relu(F.conv3d(x, w, b, stride, pad)), [x, w, b], [False, True, True])
+
+
+def test_thin_input_conv_instnorm():
+    x = _mk(2, 1, 6, 12, 13, seed=27)
+    w = _mk(32, 1, 3, 3, 3, seed=28) / 5.0
+    b, ga, be = _mk(32, seed=29), _mk(32, seed=30), _mk(32, seed=31)
+    _run(lambda x, w, b, ga, be: ops.fused_conv3d(x, w, b, 1, 1, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
+         lambda x, w, b, ga, be: F.leaky_relu(F.instance_norm(F.conv3d(x, w, b, 1, 1), weight=ga, bias=be), 0.01),
+         [x, w, b, ga, be], [False, True, True, True, True])
+
+
+@pytest.mark.parametrize("Di,scale", [(5, 4), (7, 2), (1, 3)])
+def test_upsample_depth(Di, scale):
+    x = _mk(2, 32, Di, 6, 7, seed=32)
+    _run(lambda x: ops.upsample_depth(x, scale),
+         lambda x: F.interpolate(x, scale_factor=(scale, 1, 1), mode="trilinear", align_corners=True), [x], [True])
+
+
+def test_rejects_cpu_tensors():
+    from rehrseg_amd.lib import RehrsegHipError
+    with pytest.raises(RehrsegHipError):
+        ops.fused_conv3d(torch.randn(1, 32, 2, 4, 4), torch.randn(32, 32, 3, 3, 3), None, 1, 1)
