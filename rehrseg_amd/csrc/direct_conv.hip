@@ -218,7 +218,16 @@ extern "C" int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* dp, void
   if (d.stats_mode != 0 && !d.stats) return REHR_EINVAL;
   const int T = d.KD * d.KH * d.KW;
   const size_t smem = (size_t)d.Cin * T * d.Cout * sizeof(float);
-  if (smem > 64 * 1024) return REHR_ENOSUP;
+  if (smem > 150 * 1024) return REHR_ENOSUP;
+  if (smem > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_cin_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        return REHR_EHIP;
+      attr_set = true;
+    }
+  }
   const int groups = d.Cout / 16;
   const int vpb = 64 * (4 / groups);
   const int64_t ovox = (int64_t)d.Do * d.Ho * d.Wo;

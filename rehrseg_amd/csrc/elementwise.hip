@@ -346,8 +346,8 @@ __global__ void upsample_depth_bwd_kernel(const float* __restrict__ dy, float* _
     const int64_t r = i / plane;
     const int id = (int)(r % Di), n = (int)(r / Di);
     int lo = (int)floorf((float)(id - 1) * inv) - 1, hi = (int)ceilf((float)(id + 1) * inv) + 1;
-    if (lo < 0) lo = 0;
-    if (hi > Do - 1) hi = Do - 1;
+    if (lo < 0 || Di == 1) lo = 0;
+    if (hi > Do - 1 || Di == 1) hi = Do - 1;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int od = lo; od <= hi; ++od) {
       int i0, i1;
