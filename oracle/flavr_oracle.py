@@ -1,0 +1,142 @@
+"""Functional CPU restatement of the FLAVR 3D U-Net (TEST INFRASTRUCTURE).
+
+Follows, operation by operation, the reference's
+  models/FLAVR/FLAVR_arch.py:117-248  (UNet_3D_3D: ctor wiring and forward)
+  models/FLAVR/resnet_3D.py:42-50     (BasicStem), :100-116 (SEGating),
+  models/FLAVR/resnet_3D.py:118-151   (BasicBlock), :153-210 (VideoResNet layers)
+written against a plain state-dict with torch.nn.functional so that it shares no
+module code with either the reference or the HIP product.  Pinned by
+tests/golden/flavr_*.npz, which tools/gen_golden.py produced by running the
+reference itself in the build container.
+"""
+import torch
+import torch.nn.functional as F
+
+NF = (512, 256, 128, 64)  # FLAVR_arch.py:121
+
+
+def se_gating(x, w, b):
+    """resnet_3D.py:112-116: x * sigmoid(conv1x1x1(global_avg_pool(x)))."""
+    pooled = x.mean(dim=(2, 3, 4), keepdim=True)
+    return x * torch.sigmoid(F.conv3d(pooled, w, b))
+
+
+def _block(sd, p, x, stride):
+    """resnet_3D.py:140-151; conv bias only exists when useBias was set (:8,:33)."""
+    out = torch.relu(F.conv3d(x, sd[p + "conv1.0.weight"], sd.get(p + "conv1.0.bias"), stride, 1))
+    out = F.conv3d(out, sd[p + "conv2.0.weight"], sd.get(p + "conv2.0.bias"), 1, 1)
+    out = se_gating(out, sd[p + "fg.attn_layer.0.weight"], sd[p + "fg.attn_layer.0.bias"])
+    res = x
+    if (p + "downsample.0.weight") in sd:  # resnet_3D.py:196-200 (never has a bias)
+        res = F.conv3d(x, sd[p + "downsample.0.weight"], None, stride)
+    return torch.relu(out + res)
+
+
+def encoder(sd, x, prefix="encoder."):
+    """resnet_3D.py:183-189 with unet_18's layout (:238-261): strides (1,1,1),
+    (1,2,2), (1,2,2), (1,1,1); depth is never reduced."""
+    x0 = torch.relu(F.conv3d(x, sd[prefix + "stem.0.weight"], sd.get(prefix + "stem.0.bias"), (1, 2, 2), (1, 3, 3)))
+    feats = [x0]
+    cur = x0
+    for li, stride in ((1, (1, 1, 1)), (2, (1, 2, 2)), (3, (1, 2, 2)), (4, (1, 1, 1))):
+        cur = _block(sd, f"{prefix}layer{li}.0.", cur, stride)
+        cur = _block(sd, f"{prefix}layer{li}.1.", cur, (1, 1, 1))
+        feats.append(cur)
+    return tuple(feats)
+
+
+def _dec_conv(sd, i, x):
+    """FLAVR_arch.py:72-88 Conv_3d = Conv3d(k3,p1,bias) -> SEGating."""
+    p = f"decoder.{i}.conv."
+    y = F.conv3d(x, sd[p + "0.weight"], sd[p + "0.bias"], 1, 1)
+    return se_gating(y, sd[p + "1.attn_layer.0.weight"], sd[p + "1.attn_layer.0.bias"])
+
+
+def _dec_up(sd, i, x):
+    """FLAVR_arch.py:40-70 upConv3D(transpose) = ConvTranspose3d((3,4,4),(1,2,2),(1,1,1)) -> SEGating."""
+    p = f"decoder.{i}.upconv."
+    y = F.conv_transpose3d(x, sd[p + "0.weight"], sd[p + "0.bias"], (1, 2, 2), (1, 1, 1))
+    return se_gating(y, sd[p + "1.attn_layer.0.weight"], sd[p + "1.attn_layer.0.bias"])
+
+
+def unet_3d_3d(sd, images, img_channels, n_inputs, n_outputs, use_uncertainty=False,
+               return_intermediate_feature=False):
+    """FLAVR_arch.py:169-248.  NOTE: like the reference (:180-181) this subtracts
+    the mean of channel 0 from `images` IN PLACE."""
+    lrelu = lambda t: F.leaky_relu(t, 0.2)
+    mean_ = images[:, 0:1].mean(2, keepdim=True).mean(3, keepdim=True).mean(4, keepdim=True)
+    images[:, 0:1] = images[:, 0:1] - mean_
+    x0, x1, x2, x3, x4 = encoder(sd, images)
+    if return_intermediate_feature:
+        return x0, x1, x2, x3, x4
+    d3 = torch.cat([lrelu(_dec_conv(sd, 0, x4)), x3], 1)
+    d2 = torch.cat([lrelu(_dec_up(sd, 1, d3)), x2], 1)
+    d1 = torch.cat([lrelu(_dec_up(sd, 2, d2)), x1], 1)
+    d0 = torch.cat([lrelu(_dec_conv(sd, 3, d1)), x0], 1)
+    dout = lrelu(_dec_up(sd, 4, d0))
+    dout = torch.cat(torch.unbind(dout, 2), 1)  # depth -> channels (:201)
+
+    if use_uncertainty:  # :203-227, :244-246
+        dout = lrelu(F.conv2d(dout, sd["feature_fuse.conv.0.weight"], sd["feature_fuse.conv.0.bias"], 1, 1))
+        out = F.conv2d(dout, sd["feature_fuse1.conv.0.weight"], sd["feature_fuse1.conv.0.bias"])
+        out = torch.stack(torch.split(out, out.shape[1] // n_outputs, dim=1), dim=2)
+        ue = F.conv2d(dout, sd["uncertainty_early.conv.0.weight"], sd["uncertainty_early.conv.0.bias"])
+        ue = torch.stack(torch.split(ue, ue.shape[1] // n_outputs, dim=1), dim=2)
+        sm = torch.softmax(ue, dim=1)
+        total = 0
+        for i in range(sm.shape[1]):
+            img = (torch.tanh(out[:, 2 * i:2 * i + 1]) + 1) / 2 * sm[:, i:i + 1]
+            seg = out[:, 2 * i + 1:2 * i + 2] * sm[:, i:i + 1]
+            total = total + torch.cat([img, seg], dim=1)
+        unc = torch.sigmoid(F.conv3d(sm, sd["uncertainty_out.weight"], sd["uncertainty_out.bias"]))
+        return total, unc
+
+    out = lrelu(F.conv2d(dout, sd["feature_fuse.conv.0.weight"], sd["feature_fuse.conv.0.bias"], 1, 1))
+    out = F.conv2d(F.pad(out, (3, 3, 3, 3), mode="reflect"), sd["outconv.1.weight"], sd["outconv.1.bias"])
+    outs = torch.split(out, img_channels, dim=1)
+    m2 = mean_.squeeze(2)
+    if img_channels > 1:
+        outs = [torch.cat([torch.tanh(o[:, 0:1] + m2), o[:, 1:2]], dim=1) for o in outs]
+    else:
+        outs = [o + m2 for o in outs]
+    return torch.stack(outs, dim=2)
+
+
+def flavr_shapes(img_channels, n_inputs, n_outputs, use_uncertainty=False, enc_bias=None):
+    """Parameter name -> shape of UNet_3D_3D(img_channels,'unet_18',n_inputs,n_outputs)
+    (FLAVR_arch.py:118-156; encoder convs carry a bias iff n_outputs > 1, :133-134)."""
+    if enc_bias is None:
+        enc_bias = n_outputs > 1
+    s = {}
+
+    def conv(name, co, ci, k, bias):
+        s[name + ".weight"] = (co, ci) + tuple(k)
+        if bias:
+            s[name + ".bias"] = (co,)
+
+    conv("encoder.stem.0", 64, img_channels, (3, 7, 7), enc_bias)
+    inp = 64
+    for li, planes in ((1, 64), (2, 128), (3, 256), (4, 512)):
+        for bi in (0, 1):
+            p = f"encoder.layer{li}.{bi}."
+            conv(p + "conv1.0", planes, inp if bi == 0 else planes, (3, 3, 3), enc_bias)
+            conv(p + "conv2.0", planes, planes, (3, 3, 3), enc_bias)
+            conv(p + "fg.attn_layer.0", planes, planes, (1, 1, 1), True)
+            if bi == 0 and li > 1:
+                conv(p + "downsample.0", planes, inp, (1, 1, 1), False)
+        inp = planes
+    conv("decoder.0.conv.0", 256, 512, (3, 3, 3), True)
+    conv("decoder.0.conv.1.attn_layer.0", 256, 256, (1, 1, 1), True)
+    for i, (ci, co) in ((1, (512, 128)), (2, (256, 64)), (4, (128, 64))):
+        s[f"decoder.{i}.upconv.0.weight"] = (ci, co, 3, 4, 4)
+        s[f"decoder.{i}.upconv.0.bias"] = (co,)
+        conv(f"decoder.{i}.upconv.1.attn_layer.0", co, co, (1, 1, 1), True)
+    conv("decoder.3.conv.0", 64, 128, (3, 3, 3), True)
+    conv("decoder.3.conv.1.attn_layer.0", 64, 64, (1, 1, 1), True)
+    conv("feature_fuse.conv.0", 64 * n_inputs if use_uncertainty else 64, 64 * n_inputs, (3, 3), True)
+    conv("feature_fuse1.conv.0", 64 * img_channels, 64 * n_inputs, (1, 1), True)
+    if use_uncertainty:
+        conv("uncertainty_early.conv.0", 64, 64 * n_inputs, (1, 1), True)
+        conv("uncertainty_out", 1, 64 // n_outputs, (1, 1, 1), True)
+    conv("outconv.1", img_channels * n_outputs, 64, (7, 7), True)
+    return s
