@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 3D patches/sec, FLAVR UNet_3D_3D training step on one
+1x1x128x128x128 fp32 patch per GPU (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = x.clone -> forward -> L1 loss -> backward -> (N>1: RCCL gradient all-reduce)
+-> Adam update.  Inputs are synthetic and resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build_model(n_inputs, dev):
+    from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+    torch.manual_seed(0)
+    return UNet_3D_3D(img_channels=1, block="unet_18", n_inputs=n_inputs, n_outputs=4).to(dev)
+
+
+def cpu_baseline(size):
+    """The oracle (a CPU port of the reference's path) on the host cores, one step."""
+    from oracle import flavr_oracle as fo
+    torch.manual_seed(0)
+    shapes = fo.flavr_shapes(1, size, 4)
+    sd = {}
+    for k, s in shapes.items():
+        t = torch.randn(s) * (0.02 if len(s) > 1 else 0.0)
+        sd[k] = t.requires_grad_()
+    x = torch.rand(1, 1, size, size, size)
+    tgt = torch.rand(1, 1, 4, size, size)
+    t0 = time.perf_counter()
+    out = fo.unet_3d_3d(sd, x, 1, size, 4)
+    loss = (out - tgt).abs().mean()
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 forward+backward step of the same 1x1x{size}^3 fp32 workload through oracle/flavr_oracle.py "
+                      f"({dt:.1f} s, no optimizer)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=128, help="patch edge (128 = BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from rehrseg_amd import hip_backend
+    from rehrseg_amd.parallel import PatchParallel
+
+    size = args.size
+    model = build_model(size, dev)
+    pp = PatchParallel(model)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # every rank draws its own patch
+    x = torch.rand(1, 1, size, size, size, generator=g).to(dev)
+    tgt = torch.rand(1, 1, 4, size, size, generator=g).to(dev)
+
+    def step():
+        pp.zero_grad()
+        out = model(x.clone())  # forward subtracts the mean in place, like the reference
+        loss = (out - tgt).abs().mean()
+        loss.backward()
+        pp.reduce_gradients()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        hip_backend.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = hip_backend.profile_stop() if not args.no_kernel_timing else {}
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        rec = {
+            "metric": "3D patches/sec (fwd+bwd, 128^3 fp32)", "value": world * args.steps / elapsed,
+            "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FLAVR UNet_3D_3D(1,'unet_18',{size},4) fwd+bwd+Adam, 1x1x{size}^3 patch per GPU, "
+                                   "random-init weights", "patches_per_gpu": 1, "global_batch": world,
+                       "parallelism": f"dp{world} (patch-parallel, flat-bucket RCCL all-reduce)"},
+            "loss": float(loss.item()),
+        }
+        gg = prof.get("gather_gemm")
+        if gg:
+            ach = gg["flops"] / gg["seconds"] / 1e12
+            rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "gather_gemm_kernel (fp32 MFMA implicit GEMM: conv fwd/dgrad, convT fwd/dgrad)",
+                               "launches_per_step": gg["launches"] / args.steps,
+                               "avg_launch_ms": gg["seconds"] / gg["launches"] * 1e3,
+                               "algorithmic_gflop_per_step": gg["flops"] / args.steps / 1e9}
+            wg = prof.get("wgrad")
+            if wg:
+                a2 = wg["flops"] / wg["seconds"] / 1e12
+                rec["roofline_wgrad"] = {"bound": "mfma", "achieved": a2, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": a2 / FP32_MFMA_PEAK_TFLOPS,
+                                         "launches_per_step": wg["launches"] / args.steps,
+                                         "algorithmic_gflop_per_step": wg["flops"] / args.steps / 1e9}
+            tot = sum(v["seconds"] for v in prof.values())
+            rec["mfma_kernel_ms_per_step"] = tot / args.steps * 1e3
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(size)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

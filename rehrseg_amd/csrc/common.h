@@ -7,10 +7,23 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Launch bookkeeping.  hipGetLastError() is sticky per thread and may still hold
+// an unrelated, harmless error from the host framework's own start-up; every
+// launch therefore clears it first and records only its own outcome.
+static thread_local int rehr_launch_failed = 0;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)           \
+  do {                                                                                              \
+    (void)hipGetLastError();                                                                        \
+    kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);              \
+    if (hipGetLastError() != hipSuccess) rehr_launch_failed = 1;                                    \
+  } while (0)
 #define REHR_LAUNCH_CHECK()                                   \
   do {                                                        \
-    hipError_t e__ = hipGetLastError();                       \
-    if (e__ != hipSuccess) return REHR_EHIP;                  \
+    if (rehr_launch_failed) {                                 \
+      rehr_launch_failed = 0;                                 \
+      return REHR_EHIP;                                       \
+    }                                                         \
   } while (0)
 
 // Bijective XCD-aware remap of a 1-D grid: blocks that the dispatcher places on

@@ -20,6 +20,48 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-launch timing of the MFMA kernels (bench.py's roofline line): HIP
+# events recorded on the launch stream around every gather-GEMM / wgrad launch.
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = []
+
+
+def profile_stop():
+    """-> {family: {"flops", "seconds", "launches"}} summed over the recorded launches."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for fam, flops, e0, e1 in rec or []:
+        d = out.setdefault(fam, {"flops": 0.0, "seconds": 0.0, "launches": 0})
+        d["flops"] += flops
+        d["seconds"] += e0.elapsed_time(e1) * 1e-3
+        d["launches"] += 1
+    return out
+
+
+class _timed:
+    def __init__(self, fam, flops):
+        self.fam, self.flops = fam, flops
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.e1.record()
+            _prof.append((self.fam, self.flops, self.e0, self.e1))
+        return False
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -76,7 +118,9 @@ def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d.bias, d.act, d.slope = _ptr(bias), act, slope
     d.stats, d.stats_mode = _ptr(stats), stats_mode
     d.tile_d, d.tile_h, d.tile_w = tile
-    L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
+    flops = 2.0 * d.N * d.Ld * d.Lh * d.Lw * taps[0][0] * taps[1][0] * taps[2][0] * Cin * Cout
+    with _timed("gather_gemm", flops):
+        L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
 
 
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):
@@ -101,7 +145,9 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
         L.check(int(nbytes), "rehr_wgrad_workspace_bytes")
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
     d.workspace, d.workspace_bytes = _ptr(ws), nbytes
-    L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
+    flops = 2.0 * N * d.Ld * d.Lh * d.Lw * taps[0][0] * taps[1][0] * taps[2][0] * Ca * Cg
+    with _timed("wgrad", flops):
+        L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
 
 
 def _direct_desc(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
