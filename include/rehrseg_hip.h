@@ -250,6 +250,8 @@ int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_t C,
 
 /* ABI version, bumped on any signature change. */
 int rehr_abi_version(void);
+/* Text of the last HIP launch error seen on the calling thread (diagnostics). */
+const char* rehr_last_hip_error(void);
 
 #ifdef __cplusplus
 }

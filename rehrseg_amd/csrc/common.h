@@ -11,12 +11,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // an unrelated, harmless error from the host framework's own start-up; every
 // launch therefore clears it first and records only its own outcome.
 static thread_local int rehr_launch_failed = 0;
+extern thread_local int rehr_last_hip_error_code;  // defined in elementwise.hip
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)           \
   do {                                                                                              \
     (void)hipGetLastError();                                                                        \
     kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);              \
-    if (hipGetLastError() != hipSuccess) rehr_launch_failed = 1;                                    \
+    hipError_t e__ = hipGetLastError();                                                             \
+    if (e__ != hipSuccess) { rehr_launch_failed = 1; rehr_last_hip_error_code = (int)e__; }         \
   } while (0)
 #define REHR_LAUNCH_CHECK()                                   \
   do {                                                        \

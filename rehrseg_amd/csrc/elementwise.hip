@@ -468,7 +468,11 @@ inline int64_t rows_per_block_for(int64_t S, int C, int N) {
 
 #define ST ((hipStream_t)stream)
 
+thread_local int rehr_last_hip_error_code = 0;
 extern "C" int rehr_abi_version(void) { return 1; }
+extern "C" const char* rehr_last_hip_error(void) {
+  return hipGetErrorString((hipError_t)rehr_last_hip_error_code);
+}
 
 extern "C" int rehr_pack_weights_f32(const float* in, float* out, int32_t A, int32_t Apad, int32_t B,
                                      int32_t T, int32_t transpose_ab, void* stream) {

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "rehr_nchw_to_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "rehr_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "rehr_abi_version": (C.c_int, []),
+    "rehr_last_hip_error": (C.c_char_p, []),
 }
 
 _ERR = {-1: "REHR_EINVAL (malformed descriptor)", -2: "REHR_ENOSUP (unsupported shape)",
@@ -132,6 +133,12 @@ def load() -> C.CDLL:
         raise RehrsegHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    # The library's code objects must register with the HIP runtime torch already
+    # initialised: dlopen-ing it first leaves the process with a runtime that reports
+    # "no ROCm-capable device" at the first launch (observed on the MI355X box).
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
@@ -146,4 +153,7 @@ def load() -> C.CDLL:
 
 def check(rc: int, what: str):
     if rc != 0:
-        raise RehrsegHipError(f"{what} failed: {_ERR.get(rc, rc)}")
+        detail = ""
+        if rc == -3 and _lib is not None:
+            detail = f": {_lib.rehr_last_hip_error().decode()}"
+        raise RehrsegHipError(f"{what} failed: {_ERR.get(rc, rc)}{detail}")
