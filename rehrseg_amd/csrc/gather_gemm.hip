@@ -116,9 +116,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Taps that no row of this tile can reach are skipped outright (block-uniform):
+  // boundary tiles drop their padding taps, and a contraction whose source is thin
+  // along an axis (feature_fuse's input gradient: depth-1 dY against 128 depth taps)
+  // does 1/128 of the nominal work.
+  int olo[3], ohi[3];
+  if (linear) {
+    const int f0 = mt * BM;
+    int f1 = f0 + BM - 1;
+    if (f1 > d.Ld * lhw - 1) f1 = d.Ld * lhw - 1;
+    const int d0 = f0 / lhw, d1 = f1 / lhw;
+    olo[0] = d0; ohi[0] = d1;
+    olo[1] = 0; ohi[1] = d.Lh - 1; olo[2] = 0; ohi[2] = d.Lw - 1;
+    if (d0 == d1) {
+      const int h0 = (f0 - d0 * lhw) / d.Lw, h1 = (f1 - d0 * lhw) / d.Lw;
+      olo[1] = h0; ohi[1] = h1;
+      if (h0 == h1) { olo[2] = f0 - d0 * lhw - h0 * d.Lw; ohi[2] = f1 - d0 * lhw - h0 * d.Lw; }
+    }
+  } else {
+    olo[0] = tz * d.tile_d; ohi[0] = min(olo[0] + d.tile_d, d.Ld) - 1;
+    olo[1] = ty * d.tile_h; ohi[1] = min(olo[1] + d.tile_h, d.Lh) - 1;
+    olo[2] = tx * d.tile_w; ohi[2] = min(olo[2] + d.tile_w, d.Lw) - 1;
+  }
+  auto clip = [](const rehr_axis_taps& t, int s, int b, int lo, int hi, int size, int& j0, int& j1) {
+    j0 = t.count; j1 = -1;
+    const int plo = lo * s + b + t.off0, phi = hi * s + b + t.off0;
+    for (int j = 0; j < t.count; ++j) {
+      const int a = plo + t.offs * j, c = phi + t.offs * j;  // source interval of the tile for tap j
+      if (c >= 0 && a <= size - 1) { if (j < j0) j0 = j; j1 = j; }
+    }
+  };
+  int jd0, jd1, jh0, jh1, jw0, jw1;
+  clip(d.td, d.sd, d.bd, olo[0], ohi[0], d.Di, jd0, jd1);
+  clip(d.th, d.sh, d.bh, olo[1], ohi[1], d.Hi, jh0, jh1);
+  clip(d.tw, d.sw, d.bw, olo[2], ohi[2], d.Wi, jw0, jw1);
+  const bool any_tap = jd1 >= jd0 && jh1 >= jh0 && jw1 >= jw0;
+
   // K-step iterator: channel chunk outermost, then jd, jh, jw (innermost)
-  int cc = 0, jd = 0, jh = 0, jw = 0;
-  const int nsteps = p.kchunks * d.td.count * d.th.count * d.tw.count;
+  int cc = 0, jd = jd0, jh = jh0, jw = jw0;
+  const int nsteps = any_tap ? p.kchunks * (jd1 - jd0 + 1) * (jh1 - jh0 + 1) * (jw1 - jw0 + 1) : 0;
 
   f32x4 ra[AROWS], rb[BROWS];
 
@@ -149,11 +185,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
     for (int i = 0; i < BROWS; ++i)
       rb[i] = *reinterpret_cast<const f32x4*>(wbase + (int64_t)(r0 + 32 * i) * d.Cin);
     // advance iterator
-    if (++jw == d.tw.count) {
-      jw = 0;
-      if (++jh == d.th.count) {
-        jh = 0;
-        if (++jd == d.td.count) { jd = 0; cc += BK; }
+    if (++jw > jw1) {
+      jw = jw0;
+      if (++jh > jh1) {
+        jh = jh0;
+        if (++jd > jd1) { jd = jd0; cc += BK; }
       }
     }
   };
@@ -168,8 +204,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
       *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDS_LD + q * 4) = rb[i];
   };
 
-  issue_loads();
-  commit_loads(0);
+  if (nsteps > 0) {
+    issue_loads();
+    commit_loads(0);
+  }
   __syncthreads();
 
   const int arow = wm * WTM + (lane & 31);

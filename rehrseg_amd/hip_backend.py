@@ -8,6 +8,7 @@ device memory and streams only; all arithmetic happens in librehrseg_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import torch
 
@@ -42,6 +43,27 @@ def profile_stop():
         d["seconds"] += e0.elapsed_time(e1) * 1e-3
         d["launches"] += 1
     return out
+
+
+@functools.lru_cache(maxsize=4096)
+def _reach(L, s, b, taps, size):
+    """Number of (lattice point, tap) pairs of one axis whose source index is in bounds:
+    the algorithmic work of a launch excludes taps that fall into the zero padding."""
+    cnt, off0, offs, _, _ = taps
+    tot = 0
+    for j in range(cnt):
+        c = b + off0 + offs * j
+        lo = max(0, -(c // s)) if c < 0 else 0          # smallest o with o*s + c >= 0
+        hi = min(L - 1, (size - 1 - c) // s) if size - 1 - c >= 0 else -1
+        tot += max(0, hi - lo + 1)
+    return tot
+
+
+def _algo_flops(N, lattice, s, b, taps, dims, c_a, c_b):
+    f = 2.0 * N * c_a * c_b
+    for a in range(3):
+        f *= _reach(lattice[a], s[a], b[a], tuple(taps[a]), dims[a])
+    return f
 
 
 class _timed:
@@ -118,7 +140,7 @@ def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d.bias, d.act, d.slope = _ptr(bias), act, slope
     d.stats, d.stats_mode = _ptr(stats), stats_mode
     d.tile_d, d.tile_h, d.tile_w = tile
-    flops = 2.0 * d.N * d.Ld * d.Lh * d.Lw * taps[0][0] * taps[1][0] * taps[2][0] * Cin * Cout
+    flops = _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
     with _timed("gather_gemm", flops):
         L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
 
@@ -145,7 +167,7 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
         L.check(int(nbytes), "rehr_wgrad_workspace_bytes")
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
     d.workspace, d.workspace_bytes = _ptr(ws), nbytes
-    flops = 2.0 * N * d.Ld * d.Lh * d.Lw * taps[0][0] * taps[1][0] * taps[2][0] * Ca * Cg
+    flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
     with _timed("wgrad", flops):
         L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
 
