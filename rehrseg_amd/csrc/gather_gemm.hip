@@ -34,6 +34,7 @@ struct GGParams {
   rehr_gather_gemm_desc d;
   int tiles_d, tiles_h, tiles_w, m_tiles, n_tiles;
   int kchunks;  // Cin / 32
+  int64_t wp_bytes;
 };
 
 template <int BM, int BN, int WGM, int WGN>
@@ -158,40 +159,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
 
   f32x4 ra[AROWS], rb[BROWS];
 
+  // Branch-free gather: raw buffer loads return 0 for an offset >= num_records, so a
+  // tap that leaves the source (zero padding) is just an out-of-range offset.  The
+  // whole K-step body is then one basic block and the address arithmetic of the next
+  // tile schedules into the shadow of the current tile's MFMAs.
+  const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
+  const uint32_t nrec1 = img_elems * (uint32_t)d.ldx1 * 4u;
+  const uint32_t nrec2 = d.x2 ? img_elems * (uint32_t)d.ldx2 * 4u : nrec1;
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.x1) + img_vox * d.ldx1, 0, nrec1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = d.x2 ? __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.x2) + img_vox * d.ldx2, 0, nrec2, 0x00020000) : rs1;
+  const uint32_t nrecw = (uint32_t)p.wp_bytes;
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wp), 0, nrecw, 0x00020000);
+  int rowvox[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i)
+    rowvox[i] = (sd0[i] < 0 && sd0[i] < -(1 << 20)) ? 0 : (sd0[i] * d.Hi + sh0[i]) * d.Wi + sw0[i];
+  const uint32_t brow_off = (uint32_t)(n0 + r0) * d.Cin * 4u + q * 16u;
+
   auto issue_loads = [&]() {
     const int dd = d.td.off0 + d.td.offs * jd;
     const int dh = d.th.off0 + d.th.offs * jh;
     const int dw = d.tw.off0 + d.tw.offs * jw;
-    const float* src;
-    int ld, coff;
-    if (cc < d.c1) { src = d.x1; ld = d.ldx1; coff = cc; }
-    else           { src = d.x2; ld = d.ldx2; coff = cc - d.c1; }
+    const int tapvox = (dd * d.Hi + dh) * d.Wi + dw;
+    const bool first = cc < d.c1;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;
+    const uint32_t ldb = (uint32_t)(first ? d.ldx1 : d.ldx2) * 4u;
+    const uint32_t cb = (uint32_t)((first ? cc : cc - d.c1) + q * 4) * 4u;
+    const uint32_t oob = first ? nrec1 : nrec2;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int id = sd0[i] + dd, ih = sh0[i] + dh, iw = sw0[i] + dw;
-      const bool inb = (unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi &&
-                       (unsigned)iw < (unsigned)d.Wi;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (inb) {
-        const int64_t vox = img_vox + ((int64_t)id * d.Hi + ih) * d.Wi + iw;
-        v = *reinterpret_cast<const f32x4*>(src + vox * ld + coff + q * 4);
-      }
-      ra[i] = v;
+      const bool inb = ((unsigned)id < (unsigned)d.Di) & ((unsigned)ih < (unsigned)d.Hi) &
+                       ((unsigned)iw < (unsigned)d.Wi);  // bitwise: no short-circuit branches
+      const uint32_t lin = (uint32_t)(rowvox[i] + tapvox) * ldb + cb;
+      const uint32_t off = inb ? lin : oob;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
     const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW +
                    (d.tw.k0 + d.tw.ks * jw);
-    const float* wbase = d.wp + ((int64_t)wt * d.Npad + n0) * d.Cin + cc + q * 4;
+    const uint32_t woff = ((uint32_t)wt * d.Npad * d.Cin + cc) * 4u + brow_off;
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
-      rb[i] = *reinterpret_cast<const f32x4*>(wbase + (int64_t)(r0 + 32 * i) * d.Cin);
-    // advance iterator
-    if (++jw > jw1) {
-      jw = jw0;
-      if (++jh > jh1) {
-        jh = jh0;
-        if (++jd > jd1) { jd = jd0; cc += BK; }
-      }
-    }
+      rb[i] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (uint32_t)(32 * i) * d.Cin * 4u, 0, 0));
+    // advance iterator (scalar)
+    ++jw;
+    const bool cw = jw > jw1;
+    jw = cw ? jw0 : jw;
+    jh += cw ? 1 : 0;
+    const bool ch = jh > jh1;
+    jh = ch ? jh0 : jh;
+    jd += ch ? 1 : 0;
+    const bool cd = jd > jd1;
+    jd = cd ? jd0 : jd;
+    cc += cd ? BK : 0;
   };
   auto commit_loads = [&](int buf) {
     float* a = As + buf * BM * LDS_LD;
@@ -216,8 +240,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
 
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    const bool more = (s + 1) < nsteps;
-    if (more) issue_loads();
+    // Always fetch and stage one tile ahead, also after the last step (the iterator
+    // has then run past Cin: every such load is out of range or harmless, and the
+    // staged tile is never read) -- this keeps the loop body free of branches.
+    issue_loads();
 
     const float* a = As + buf * BM * LDS_LD;
     const float* b = Bs + buf * BN * LDS_LD;
@@ -238,7 +264,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
           for (int j = 0; j < FN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
-    if (more) commit_loads(buf ^ 1);
+    commit_loads(buf ^ 1);
     __syncthreads();
   }
 
@@ -336,6 +362,18 @@ extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* strea
     p.m_tiles = p.tiles_d * p.tiles_h * p.tiles_w;
   }
   p.kchunks = d.Cin / 32;
+  {
+    // buffer-addressed operands: 32-bit byte offsets per sample / per weight panel
+    const int64_t kd_max = d.td.k0 + (int64_t)d.td.ks * (d.td.count - 1);
+    const int64_t kh_max = d.th.k0 + (int64_t)d.th.ks * (d.th.count - 1);
+    const int64_t kw_max = d.tw.k0 + (int64_t)d.tw.ks * (d.tw.count - 1);
+    const int64_t taps_all = ((kd_max * d.KH) + kh_max) * d.KW + kw_max + 1;
+    p.wp_bytes = taps_all * d.Npad * d.Cin * 4;
+    const int64_t img = (int64_t)d.Di * d.Hi * d.Wi * 4;
+    if (p.wp_bytes >= (1ll << 32) - 64 || img * d.ldx1 >= (1ll << 32) - 64 ||
+        (d.x2 && img * d.ldx2 >= (1ll << 32) - 64))
+      return REHR_ENOSUP;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (d.Npad % 128 == 0) {
     p.n_tiles = d.Npad / 128;

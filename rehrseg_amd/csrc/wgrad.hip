@@ -13,12 +13,35 @@
 // is exactly the MFMA A/B register order for k = voxel: lane l reads
 // tile[k = 2*step + (l>>5)][i = l&31] with a conflict-free ds_read_b32, no
 // transposition anywhere.
+//
+// The K-step body is one basic block: raw buffer loads return 0 for an offset
+// past num_records (tail of a split, taps that leave the source), and the lattice
+// coordinates of a row come from multiply-high "magic" divisions, so the address
+// arithmetic of the next tile schedules into the shadow of the current MFMAs.
 #include "common.h"
 
 namespace {
 
-constexpr int BKV = 32;  // lattice voxels per K step
 constexpr int NTHREADS = 256;
+
+struct Magic {  // q = n / d for 0 <= n < 2^31
+  uint32_t m;
+  uint32_t sh;  // 255: d == 1
+};
+inline Magic make_magic(uint32_t d) {
+  Magic g;
+  if (d <= 1) { g.m = 0; g.sh = 255; return g; }
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  if (s < 1) s = 1;
+  g.m = (uint32_t)(((1ull << (31 + s)) / d) + 1);
+  g.sh = s - 1;
+  return g;
+}
+__device__ __forceinline__ uint32_t mdiv(uint32_t n, Magic g) {
+  const uint32_t q = __umulhi(n, g.m) >> (g.sh & 31);
+  return g.sh == 255 ? n : q;
+}
 
 struct WGParams {
   rehr_wgrad_desc d;
@@ -28,10 +51,12 @@ struct WGParams {
   int splits;
   int Capad, Cgpad;   // tile-padded channel counts of the slab
   float* slab_bias;   // [splits][Ca] or null
+  Magic mg_vox, mg_hw, mg_w;
+  uint32_t g_bytes;
 };
 
-// BA x BG output tile, 4 waves as WGA x WGG
-template <int BA, int BG, int WGA, int WGG>
+// BA x BG output tile, 4 waves as WGA x WGG x WGK (WGK waves split the K tile)
+template <int BA, int BG, int WGA, int WGG, int BKV>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
   constexpr int WTA = BA / WGA, WTG = BG / WGG;
   constexpr int FA = WTA / 32, FG = WTG / 32;
@@ -39,8 +64,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
   constexpr int A_TPR = BA / 4, G_TPR = BG / 4;          // threads per row
   constexpr int A_RPP = NTHREADS / A_TPR, G_RPP = NTHREADS / G_TPR;  // rows per pass
   constexpr int A_PASS = BKV / A_RPP, G_PASS = BKV / G_RPP;
-  constexpr int WGK = 4 / (WGA * WGG);  // waves sharing one output tile, splitting K
+  constexpr int WGK = 4 / (WGA * WGG);
   static_assert(WGA * WGG * WGK == 4, "4 waves");
+  static_assert(A_PASS >= 1 && G_PASS >= 1, "tile too narrow for BKV");
   constexpr int KSTEPS = (BKV / 2) / WGK;  // MFMA k-steps per wave per K tile
   const rehr_wgrad_desc& d = p.d;
 
@@ -60,15 +86,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
   const int jw = tap % d.tw.count;
   const int jh = (tap / d.tw.count) % d.th.count;
   const int jd = tap / (d.tw.count * d.th.count);
-  const int dd = d.td.off0 + d.td.offs * jd, dh = d.th.off0 + d.th.offs * jh,
-            dw = d.tw.off0 + d.tw.offs * jw;
+  const int dd = d.bd + d.td.off0 + d.td.offs * jd, dh = d.bh + d.th.off0 + d.th.offs * jh,
+            dw = d.bw + d.tw.off0 + d.tw.offs * jw;
   const int a0 = at * BA, c0 = ct * BG;
   const int split = blockIdx.y;
   const int64_t v_begin = (int64_t)split * p.kv_per_split;
   int64_t v_end = v_begin + p.kv_per_split;
   if (v_end > p.kv_total) v_end = p.kv_total;
-  const int lhw = d.Lh * d.Lw;
-  const int lvox = d.Ld * lhw;
+  const uint32_t lhw = (uint32_t)d.Lh * d.Lw;
+  const uint32_t lvox = (uint32_t)d.Ld * lhw;
 
   f32x16 acc[FA][FG];
 #pragma unroll
@@ -81,37 +107,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
 #pragma unroll
   for (int i = 0; i < FA; ++i) bsum[i] = 0.f;
   const bool do_bias = (p.slab_bias != nullptr) && tap == 0 && ct == 0 && wg == 0;  // every wk
+  const float bias_w = do_bias ? 1.f : 0.f;
+
+  // L rows of this split are addressed relative to v_begin: rows past v_end are
+  // past num_records and read as zero.
+  const int64_t nrows = v_end > v_begin ? v_end - v_begin : 0;
+  const uint32_t l_bytes = (uint32_t)(nrows * d.ldl * 4);
+  const __amdgpu_buffer_rsrc_t rl_ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.l) + v_begin * d.ldl, 0, l_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg_ =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.g), 0, p.g_bytes, 0x00020000);
 
   f32x4 rl[A_PASS], rg[G_PASS];
   const int aq = tid % A_TPR, ar = tid / A_TPR;
   const int gq = tid % G_TPR, gr = tid / G_TPR;
   const bool a_col_ok = (a0 + aq * 4) < d.Ca;   // Ca % 32 == 0 and tiles are 32-multiples
   const bool g_col_ok = (c0 + gq * 4) < d.Cg;
+  const uint32_t a_cb = (uint32_t)(a0 + aq * 4) * 4u, g_cb = (uint32_t)(c0 + gq * 4) * 4u;
+  const uint32_t ldlb = (uint32_t)d.ldl * 4u, ldgb = (uint32_t)d.ldg * 4u;
 
-  auto issue_loads = [&](int64_t vbase) {
+  auto issue_loads = [&](uint32_t rbase) {  // rbase = row offset of the tile inside the split
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      const int64_t v = vbase + ar + i * A_RPP;
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-      if (v < v_end && a_col_ok) x = *reinterpret_cast<const f32x4*>(d.l + v * d.ldl + a0 + aq * 4);
-      rl[i] = x;
+      const uint32_t row = rbase + ar + i * A_RPP;
+      const uint32_t off = a_col_ok ? row * ldlb + a_cb : l_bytes;
+      rl[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl_, off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < G_PASS; ++i) {
-      const int64_t v = vbase + gr + i * G_RPP;
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-      if (v < v_end && g_col_ok) {
-        const int n = (int)(v / lvox);
-        int rem = (int)(v - (int64_t)n * lvox);
-        const int od = rem / lhw; rem -= od * lhw;
-        const int oh = rem / d.Lw, ow = rem - oh * d.Lw;
-        const int id = od * d.sd + d.bd + dd, ih = oh * d.sh + d.bh + dh, iw = ow * d.sw + d.bw + dw;
-        if ((unsigned)id < (unsigned)d.Dg && (unsigned)ih < (unsigned)d.Hg && (unsigned)iw < (unsigned)d.Wg) {
-          const int64_t gv = (((int64_t)n * d.Dg + id) * d.Hg + ih) * d.Wg + iw;
-          x = *reinterpret_cast<const f32x4*>(d.g + gv * d.ldg + c0 + gq * 4);
-        }
-      }
-      rg[i] = x;
+      const uint32_t row = rbase + gr + i * G_RPP;
+      const uint32_t v = (uint32_t)v_begin + row;      // kv_total < 2^31 (checked on the host)
+      const uint32_t n = mdiv(v, p.mg_vox);
+      uint32_t rem = v - n * lvox;
+      const uint32_t od = mdiv(rem, p.mg_hw);
+      rem -= od * lhw;
+      const uint32_t oh = mdiv(rem, p.mg_w);
+      const uint32_t ow = rem - oh * d.Lw;
+      const int id = (int)od * d.sd + dd, ih = (int)oh * d.sh + dh, iw = (int)ow * d.sw + dw;
+      const bool inb = ((unsigned)id < (unsigned)d.Dg) & ((unsigned)ih < (unsigned)d.Hg) &
+                       ((unsigned)iw < (unsigned)d.Wg) & (row < (uint32_t)nrows) & g_col_ok;
+      const uint32_t gv = ((n * d.Dg + id) * d.Hg + ih) * d.Wg + iw;
+      const uint32_t off = inb ? gv * ldgb + g_cb : p.g_bytes;
+      rg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg_, off, 0, 0));
     }
   };
   auto commit_loads = [&](int buf) {
@@ -125,9 +162,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
       *reinterpret_cast<f32x4*>(g + (gr + i * G_RPP) * LDG + gq * 4) = rg[i];
   };
 
-  const int64_t nsteps = (v_end > v_begin) ? (v_end - v_begin + BKV - 1) / BKV : 0;
+  const int nsteps = (int)((nrows + BKV - 1) / BKV);
   if (nsteps > 0) {
-    issue_loads(v_begin);
+    issue_loads(0);
     commit_loads(0);
   }
   __syncthreads();
@@ -136,10 +173,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
   const int gcol = wg * WTG + (lane & 31);
   const int krow = lane >> 5;
 
-  for (int64_t s = 0; s < nsteps; ++s) {
-    const int buf = (int)(s & 1);
-    const bool more = (s + 1) < nsteps;
-    if (more) issue_loads(v_begin + (s + 1) * BKV);
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    issue_loads((uint32_t)(s + 1) * BKV);  // one tile ahead; past the split it reads zeros
     const float* l = Ls + buf * BKV * LDA;
     const float* g = Gs + buf * BKV * LDG;
 #pragma unroll
@@ -149,17 +185,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
       for (int i = 0; i < FA; ++i) fa[i] = l[(kk * 2 + krow) * LDA + acol + 32 * i];
 #pragma unroll
       for (int j = 0; j < FG; ++j) fg[j] = g[(kk * 2 + krow) * LDG + gcol + 32 * j];
-      if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < FA; ++i) bsum[i] += fa[i];
-      }
+      for (int i = 0; i < FA; ++i) bsum[i] += fa[i] * bias_w;  // branch-free (bias_w is 0 or 1)
 #pragma unroll
       for (int i = 0; i < FA; ++i)
 #pragma unroll
         for (int j = 0; j < FG; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fg[j], acc[i][j], 0, 0, 0);
     }
-    if (more) commit_loads(buf ^ 1);
+    commit_loads(buf ^ 1);
     __syncthreads();
   }
 
@@ -249,14 +283,17 @@ __global__ void wgrad_reduce_kernel(const WGParams p) {
 }
 
 int tile_for(int c) { return (c % 128 == 0) ? 128 : ((c % 64 == 0) ? 64 : 32); }
+int bkv_for(int t) { return t == 128 ? 32 : 64; }
 
-bool plan(const rehr_wgrad_desc& d, WGParams& p) {
-  if (!d.l || !d.g || !d.dst) return false;
-  if (d.Ca < 32 || d.Ca % 32 || d.Cg < 32 || d.Cg % 32) return false;
-  if (d.ldl % 4 || d.ldg % 4) return false;
-  if (((uintptr_t)d.l | (uintptr_t)d.g) & 15) return false;
-  if (d.N < 1 || d.Ld < 1 || d.Lh < 1 || d.Lw < 1) return false;
-  if (d.td.count < 1 || d.th.count < 1 || d.tw.count < 1) return false;
+// 0 ok, else REHR_* code
+int plan(const rehr_wgrad_desc& d, WGParams& p) {
+  if (!d.l || !d.g || !d.dst) return REHR_EINVAL;
+  if (d.Ca < 32 || d.Ca % 32 || d.Cg < 32 || d.Cg % 32) return REHR_EINVAL;
+  if (d.ldl % 4 || d.ldg % 4) return REHR_EINVAL;
+  if (((uintptr_t)d.l | (uintptr_t)d.g) & 15) return REHR_EINVAL;
+  if (d.N < 1 || d.Ld < 1 || d.Lh < 1 || d.Lw < 1) return REHR_EINVAL;
+  if (d.Dg < 1 || d.Hg < 1 || d.Wg < 1) return REHR_EINVAL;
+  if (d.td.count < 1 || d.th.count < 1 || d.tw.count < 1) return REHR_EINVAL;
   p.d = d;
   p.T = d.td.count * d.th.count * d.tw.count;
   // one tile size for both operands keeps the instantiation count small
@@ -268,18 +305,26 @@ bool plan(const rehr_wgrad_desc& d, WGParams& p) {
   p.Capad = p.a_tiles * t;
   p.Cgpad = p.c_tiles * t;
   p.kv_total = (int64_t)d.N * d.Ld * d.Lh * d.Lw;
+  const int64_t gbytes = (int64_t)d.N * d.Dg * d.Hg * d.Wg * d.ldg * 4;
+  if (p.kv_total >= (1ll << 31) - 4096 || gbytes >= (1ll << 32) - 64) return REHR_ENOSUP;
+  p.g_bytes = (uint32_t)gbytes;
+  const int bkv = bkv_for(t);
   const int64_t tiles = (int64_t)p.T * p.a_tiles * p.c_tiles;
   // aim for ~4 blocks per CU-slot (256 CUs x 2 resident) with >= 16 K steps each
   int64_t want = (2048 + tiles - 1) / tiles;
-  const int64_t max_by_k = (p.kv_total + 16 * BKV - 1) / (16 * BKV);
+  const int64_t max_by_k = (p.kv_total + 16 * bkv - 1) / (16 * bkv);
   if (want > max_by_k) want = max_by_k;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
   int64_t per = (p.kv_total + want - 1) / want;
-  per = (per + BKV - 1) / BKV * BKV;
+  per = (per + bkv - 1) / bkv * bkv;
+  if ((int64_t)per * d.ldl * 4 >= (1ll << 32) - 64) return REHR_ENOSUP;
   p.kv_per_split = per;
   p.splits = (int)((p.kv_total + per - 1) / per);
-  return true;
+  p.mg_vox = make_magic((uint32_t)(d.Ld * d.Lh * d.Lw));
+  p.mg_hw = make_magic((uint32_t)(d.Lh * d.Lw));
+  p.mg_w = make_magic((uint32_t)d.Lw);
+  return REHR_OK;
 }
 
 int64_t ws_bytes(const WGParams& p) {
@@ -288,10 +333,13 @@ int64_t ws_bytes(const WGParams& p) {
   return f * (int64_t)sizeof(float);
 }
 
-template <int B, int WGA, int WGG>
+template <int B, int WGA, int WGG, int BKV>
 int launch_wg(const WGParams& p, hipStream_t stream) {
-  const size_t smem = (size_t)2 * BKV * ((B + 4) + (B + 4)) * sizeof(float);
-  auto kern = wgrad_kernel<B, B, WGA, WGG>;
+  size_t smem = (size_t)2 * BKV * ((B + 4) + (B + 4)) * sizeof(float);
+  constexpr int WGK = 4 / (WGA * WGG);
+  constexpr size_t red = (size_t)(WGK - 1) * ((B / WGA / 32) * (B / WGG / 32) * 16 + (B / WGA / 32)) * 64 * 4;
+  if (red > smem) smem = red;
+  auto kern = wgrad_kernel<B, B, WGA, WGG, BKV>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -312,24 +360,25 @@ extern "C" int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* dp) {
   WGParams p;
   rehr_wgrad_desc d = *dp;
   if (!d.dst) d.dst = reinterpret_cast<float*>(16);  // size query may come before allocation
-  if (!plan(d, p)) return REHR_EINVAL;
+  const int rc = plan(d, p);
+  if (rc != REHR_OK) return rc;
   return ws_bytes(p);
 }
 
 extern "C" int rehr_wgrad_f32(const rehr_wgrad_desc* dp, void* stream) {
   if (!dp) return REHR_EINVAL;
   WGParams p;
-  if (!plan(*dp, p)) return REHR_EINVAL;
+  int rc = plan(*dp, p);
+  if (rc != REHR_OK) return rc;
   const rehr_wgrad_desc& d = p.d;
   if (!d.workspace || d.workspace_bytes < ws_bytes(p)) return REHR_EINVAL;
   if (p.splits > 65535) return REHR_EINVAL;
   p.slab_bias = d.dbias ? d.workspace + (int64_t)p.splits * p.T * p.Capad * p.Cgpad : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int t = p.Capad / p.a_tiles;
-  int rc;
-  if (t == 128) rc = launch_wg<128, 2, 2>(p, st);
-  else if (t == 64) rc = launch_wg<64, 2, 2>(p, st);
-  else rc = launch_wg<32, 1, 1>(p, st);
+  if (t == 128) rc = launch_wg<128, 2, 2, 32>(p, st);
+  else if (t == 64) rc = launch_wg<64, 1, 1, 64>(p, st);
+  else rc = launch_wg<32, 1, 1, 64>(p, st);
   if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
   int blocks = (int)((total + 255) / 256);
