@@ -159,6 +159,11 @@ typedef struct {
 } rehr_direct_conv_desc;
 
 int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* d, void* stream);
+/* out[n,o][k], k = ci*T + tap (order of the (Cin,kD,kH,kW) weight), zero for
+ * k >= Cin*T and in the padding; Kpad % 32 == 0.  The weight gradient of the thin
+ * conv is then rehr_wgrad_f32 with l = dY, g = out (1x1x1 taps) on the MFMA path. */
+int rehr_im2col_f32(const rehr_direct_conv_desc* d, float* out, int32_t Kpad,
+                    void* stream);
 int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc* d);
 /* dw (Cout,Cin,KD,KH,KW) = sum_{n,o} dY[n,o,co] * x[n,o*s-p+k,ci]; dbias optional */
 int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* d, float* dw,

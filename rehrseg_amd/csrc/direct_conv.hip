@@ -271,3 +271,72 @@ extern "C" int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_c
   const int T = dp->KD * dp->KH * dp->KW;
   return (int64_t)blocks * ((int64_t)dp->Cin * T + 1) * 64 * sizeof(float);
 }
+
+// ------------------------------------------------------------------ im2col for thin inputs
+// out[voxel][k], k = ci*T + tap (the weight's own (Cin,kD,kH,kW) order), zero for
+// k >= Cin*T and for taps in the padding.  With it the weight gradient of a thin-input
+// conv is a plain 1x1x1 weight gradient on the matrix cores (rehr_wgrad_f32).
+namespace {
+__global__ void im2col_kernel(const rehr_direct_conv_desc d, float* __restrict__ out, int Kpad) {
+  extern __shared__ int lut[];  // [Kpad]: ci<<24 | kd<<16 | kh<<8 | kw, -1 for padding columns
+  const int T = d.KD * d.KH * d.KW, K = d.Cin * T;
+  for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+    int v = -1;
+    if (k < K) {
+      const int ci = k / T, t = k - ci * T;
+      const int kw = t % d.KW, kh = (t / d.KW) % d.KH, kd = t / (d.KW * d.KH);
+      v = (ci << 24) | (kd << 16) | (kh << 8) | kw;
+    }
+    lut[k] = v;
+  }
+  __syncthreads();
+  const uint32_t G = (uint32_t)Kpad / 4;
+  const int64_t ovox = (int64_t)d.Do * d.Ho * d.Wo;
+  const int64_t total = (int64_t)d.N * ovox * G;
+  const int how = d.Ho * d.Wo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / G;
+    const int g = (int)(i - v * G);
+    const int n = (int)(v / ovox);
+    const int64_t r0 = v - (int64_t)n * ovox;
+    const int od = (int)(r0 / how);
+    const int rem = (int)(r0 - (int64_t)od * how);
+    const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+    const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int code = lut[g * 4 + e];
+      float val = 0.f;
+      if (code >= 0) {
+        const int ci = code >> 24, kd = (code >> 16) & 255, kh = (code >> 8) & 255, kw = code & 255;
+        const int id = od * d.sd - d.pd + kd, ih = oh * d.sh - d.ph + kh, iw = ow * d.sw - d.pw + kw;
+        if ((unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi && (unsigned)iw < (unsigned)d.Wi)
+          val = xn[(((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx + ci];
+      }
+      o[e] = val;
+    }
+    *reinterpret_cast<f32x4*>(out + v * Kpad + g * 4) = o;
+  }
+}
+}  // namespace
+
+extern "C" int rehr_im2col_f32(const rehr_direct_conv_desc* dp, float* out, int32_t Kpad, void* stream) {
+  if (!dp || !out) return REHR_EINVAL;
+  const rehr_direct_conv_desc& d = *dp;
+  if (!d.x || d.Cin < 1 || d.Cin > 127 || d.N < 1) return REHR_EINVAL;
+  if (d.KD < 1 || d.KH < 1 || d.KW < 1 || d.KD > 255 || d.KH > 255 || d.KW > 255) return REHR_EINVAL;
+  if (Kpad % 4 || Kpad < d.Cin * d.KD * d.KH * d.KW || (((uintptr_t)out) & 15)) return REHR_EINVAL;
+  if ((d.Di + 2 * d.pd - d.KD) / d.sd + 1 != d.Do || (d.Hi + 2 * d.ph - d.KH) / d.sh + 1 != d.Ho ||
+      (d.Wi + 2 * d.pw - d.KW) / d.sw + 1 != d.Wo)
+    return REHR_EINVAL;
+  const size_t smem = (size_t)Kpad * sizeof(int);
+  if (smem > 48 * 1024) return REHR_ENOSUP;
+  const int64_t total = (int64_t)d.N * d.Do * d.Ho * d.Wo * (Kpad / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, d, out, Kpad);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}

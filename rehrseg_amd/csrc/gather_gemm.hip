@@ -157,7 +157,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
   int cc = 0, jd = jd0, jh = jh0, jw = jw0;
   const int nsteps = any_tap ? p.kchunks * (jd1 - jd0 + 1) * (jh1 - jh0 + 1) * (jw1 - jw0 + 1) : 0;
 
-  f32x4 ra[AROWS], rb[BROWS];
+  // two register sets: tiles are fetched TWO K-steps ahead, so a load that misses L2
+  // (HBM latency, ~2x a K step under load) does not stall the block at the barrier
+  f32x4 ra0[AROWS], rb0[BROWS], ra1[AROWS], rb1[BROWS];
 
   // Branch-free gather: raw buffer loads return 0 for an offset >= num_records, so a
   // tap that leaves the source (zero padding) is just an out-of-range offset.  The
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
     rowvox[i] = (sd0[i] < 0 && sd0[i] < -(1 << 20)) ? 0 : (sd0[i] * d.Hi + sh0[i]) * d.Wi + sw0[i];
   const uint32_t brow_off = (uint32_t)(n0 + r0) * d.Cin * 4u + q * 16u;
 
-  auto issue_loads = [&]() {
+  auto issue_loads = [&](f32x4 (&ra)[AROWS], f32x4 (&rb)[BROWS]) {
     const int dd = d.td.off0 + d.td.offs * jd;
     const int dh = d.th.off0 + d.th.offs * jh;
     const int dw = d.tw.off0 + d.tw.offs * jw;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
     jd = cd ? jd0 : jd;
     cc += cd ? BK : 0;
   };
-  auto commit_loads = [&](int buf) {
+  auto commit_loads = [&](int buf, const f32x4 (&ra)[AROWS], const f32x4 (&rb)[BROWS]) {
     float* a = As + buf * BM * LDS_LD;
     float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -228,23 +230,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
       *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDS_LD + q * 4) = rb[i];
   };
 
-  if (nsteps > 0) {
-    issue_loads();
-    commit_loads(0);
-  }
-  __syncthreads();
-
   const int arow = wm * WTM + (lane & 31);
   const int brow = wn * WTN + (lane & 31);
   const int koff = 4 * (lane >> 5);
-
-  for (int s = 0; s < nsteps; ++s) {
-    const int buf = s & 1;
-    // Always fetch and stage one tile ahead, also after the last step (the iterator
-    // has then run past Cin: every such load is out of range or harmless, and the
-    // staged tile is never read) -- this keeps the loop body free of branches.
-    issue_loads();
-
+  auto compute = [&](int buf) {
     const float* a = As + buf * BM * LDS_LD;
     const float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -263,8 +252,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
 #pragma unroll
           for (int j = 0; j < FN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+      // the fetch issued above must leave in the shadow of the first MFMA group,
+      // not be sunk behind the whole tile
+      if (kk == 0) __builtin_amdgcn_sched_barrier(0);
     }
-    commit_loads(buf ^ 1);
+  };
+
+  if (nsteps > 0) {
+    issue_loads(ra0, rb0);  // tile 0
+    issue_loads(ra1, rb1);  // tile 1 (past the end: out-of-range / never used)
+    commit_loads(0, ra0, rb0);
+  }
+  __syncthreads();
+
+  // Invariant at the top: tile s is staged in LDS[0], tile s+1 is in flight in set 1.
+  // Fetches run past the last tile (the iterator is then beyond Cin: such loads are
+  // out of range or harmless and never consumed), which keeps each half branch-free.
+  for (int s = 0; s < nsteps; s += 2) {
+    issue_loads(ra0, rb0);            // tile s+2
+    compute(0);
+    commit_loads(1, ra1, rb1);        // tile s+1
+    __syncthreads();
+    if (s + 1 >= nsteps) break;
+    issue_loads(ra1, rb1);            // tile s+3
+    compute(1);
+    commit_loads(0, ra0, rb0);        // tile s+2
     __syncthreads();
   }
 

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
   const __amdgpu_buffer_rsrc_t rg_ =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.g), 0, p.g_bytes, 0x00020000);
 
-  f32x4 rl[A_PASS], rg[G_PASS];
+  // two register sets: tiles are fetched two K-steps ahead (HBM-latency tolerance)
+  f32x4 rl0[A_PASS], rg0[G_PASS], rl1[A_PASS], rg1[G_PASS];
   const int aq = tid % A_TPR, ar = tid / A_TPR;
   const int gq = tid % G_TPR, gr = tid / G_TPR;
   const bool a_col_ok = (a0 + aq * 4) < d.Ca;   // Ca % 32 == 0 and tiles are 32-multiples
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
   const uint32_t a_cb = (uint32_t)(a0 + aq * 4) * 4u, g_cb = (uint32_t)(c0 + gq * 4) * 4u;
   const uint32_t ldlb = (uint32_t)d.ldl * 4u, ldgb = (uint32_t)d.ldg * 4u;
 
-  auto issue_loads = [&](uint32_t rbase) {  // rbase = row offset of the tile inside the split
+  // rbase = row offset of the tile inside the split
+  auto issue_loads = [&](uint32_t rbase, f32x4 (&rl)[A_PASS], f32x4 (&rg)[G_PASS]) {
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const uint32_t row = rbase + ar + i * A_RPP;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
       rg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg_, off, 0, 0));
     }
   };
-  auto commit_loads = [&](int buf) {
+  auto commit_loads = [&](int buf, const f32x4 (&rl)[A_PASS], const f32x4 (&rg)[G_PASS]) {
     float* l = Ls + buf * BKV * LDA;
     float* g = Gs + buf * BKV * LDG;
 #pragma unroll
@@ -163,19 +165,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
   };
 
   const int nsteps = (int)((nrows + BKV - 1) / BKV);
-  if (nsteps > 0) {
-    issue_loads(0);
-    commit_loads(0);
-  }
-  __syncthreads();
-
   const int acol = wa * WTA + (lane & 31);
   const int gcol = wg * WTG + (lane & 31);
   const int krow = lane >> 5;
-
-  for (int s = 0; s < nsteps; ++s) {
-    const int buf = s & 1;
-    issue_loads((uint32_t)(s + 1) * BKV);  // one tile ahead; past the split it reads zeros
+  auto compute = [&](int buf) {
     const float* l = Ls + buf * BKV * LDA;
     const float* g = Gs + buf * BKV * LDG;
 #pragma unroll
@@ -192,8 +185,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
 #pragma unroll
         for (int j = 0; j < FG; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fg[j], acc[i][j], 0, 0, 0);
+      if (kk == wk * KSTEPS + 1) __builtin_amdgcn_sched_barrier(0);  // fetch leaves early, not after the tile
     }
-    commit_loads(buf ^ 1);
+  };
+
+  if (nsteps > 0) {
+    issue_loads(0, rl0, rg0);
+    issue_loads(BKV, rl1, rg1);  // past the split: zeros
+    commit_loads(0, rl0, rg0);
+  }
+  __syncthreads();
+
+  // top of loop: tile s staged in LDS[0], tile s+1 in flight in set 1
+  for (int s = 0; s < nsteps; s += 2) {
+    issue_loads((uint32_t)(s + 2) * BKV, rl0, rg0);
+    compute(0);
+    commit_loads(1, rl1, rg1);
+    __syncthreads();
+    if (s + 1 >= nsteps) break;
+    issue_loads((uint32_t)(s + 3) * BKV, rl1, rg1);
+    compute(1);
+    commit_loads(0, rl0, rg0);
     __syncthreads();
   }
 

@@ -194,6 +194,17 @@ def small_cin_fwd(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
     L.check(L.load().rehr_conv_small_cin_fwd_f32(C.byref(d), _stream()), "rehr_conv_small_cin_fwd_f32")
 
 
+def im2col(x, w, out_dims, stride, pad, Kpad):
+    """(N, Kpad, Do, Ho, Wo) NDHWC columns of a thin-input conv (k = ci*T + tap)."""
+    _chk_dev(x, w)
+    N = x.shape[0]
+    col = new_act(N, Kpad, *out_dims, like=x)
+    d = _direct_desc(x, w, None, col, stride, pad, 0, 0.0, None, 0)
+    d.Cout, d.ldy = w.shape[0], Kpad
+    L.check(L.load().rehr_im2col_f32(C.byref(d), _ptr(col), Kpad, _stream()), "rehr_im2col_f32")
+    return col
+
+
 def small_cin_wgrad(x, w, dy, stride, pad, want_bias):
     _chk_dev(x, w, dy)
     d = _direct_desc(x, w.contiguous(), None, dy, stride, pad, 0, 0.0, None, 0)

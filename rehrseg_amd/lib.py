@@ -82,6 +82,7 @@ PROTOTYPES = {
     "rehr_wgrad_f32": (C.c_int, [_P_WG, _vp]),
     "rehr_pack_weights_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "rehr_conv_small_cin_fwd_f32": (C.c_int, [_P_DC, _vp]),
+    "rehr_im2col_f32": (C.c_int, [_P_DC, _vp, _i32, _vp]),
     "rehr_conv_small_cin_wgrad_workspace_bytes": (_i64, [_P_DC]),
     "rehr_conv_small_cin_wgrad_f32": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),
     "rehr_se_gate_fwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),

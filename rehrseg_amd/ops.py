@@ -15,6 +15,7 @@ arithmetic step is a kernel of librehrseg_hip.so.
 """
 from __future__ import annotations
 
+import functools
 import itertools
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -84,9 +85,13 @@ def full_taps(K):
     return (K, 0, 1, 0, 1)
 
 
-def choose_tile(lattice):
+@functools.lru_cache(maxsize=None)
+def choose_tile(lattice, thin=(False, False, False)):
     """128-voxel lattice tile with the least padding (ties: smaller halo, wider w).
-    Returns (0,0,0) = runs of 128 flattened points when bricks waste > 10 % more."""
+    Returns (0,0,0) = runs of 128 flattened points when bricks waste > 10 % more.
+    An axis flagged `thin` (its source has extent 1 but several taps point at it, e.g.
+    feature_fuse's input gradient) keeps tile extent 1 there: every row of a tile then
+    uses the same single tap instead of multiplying zeros for the others."""
     Ld, Lh, Lw = lattice
     best = None
     for td in (1, 2, 4, 8, 16, 32, 64, 128):
@@ -94,13 +99,15 @@ def choose_tile(lattice):
             if 128 % (td * th):
                 continue
             tw = 128 // (td * th)
+            if (thin[0] and td > 1) or (thin[1] and th > 1) or (thin[2] and tw > 1):
+                continue
             vol = (-(-Ld // td) * td) * (-(-Lh // th) * th) * (-(-Lw // tw) * tw)
             halo = (td + 2) * (th + 2) * (tw + 2)
             key = (vol, halo, -tw)
             if best is None or key < best[0]:
                 best = (key, (td, th, tw))
     lin = -(-(Ld * Lh * Lw) // 128) * 128
-    if best[0][0] > 1.10 * lin:
+    if best is None or (best[0][0] > 1.10 * lin and not any(thin)):
         return (0, 0, 0)
     return best[1]
 
@@ -157,8 +164,10 @@ def _phased_gather(src1, src2, c1, Csrc, wp, Npad, dst, Cdst, K, stride, pad, bi
             continue
         if any(t is None for t in taps):
             continue  # no tap reaches this phase: dst keeps its zero fill
+        thin = tuple(src_dims[a] == 1 and taps[a][0] > 1 for a in range(3))
         be.gather_gemm(src1, src2, c1, src_dims, Csrc, lattice, (1, 1, 1), (0, 0, 0), taps, K[1], K[2], wp, Npad,
-                       dst, dst_dims, Cdst, stride, ph, bias, act, slope, stats, stats_mode, choose_tile(lattice))
+                       dst, dst_dims, Cdst, stride, ph, bias, act, slope, stats, stats_mode,
+                       choose_tile(tuple(lattice), thin))
 
 
 def _has_empty_phase(K, stride, pad):
@@ -198,7 +207,7 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     taps = [full_taps(k) for k in K]
     be.gather_gemm(x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), taps, K[1], K[2],
                    wp, Npad, y, out_dims, Cout, (1, 1, 1), (0, 0, 0), bias, act, slope, stats, stats_mode,
-                   choose_tile(out_dims))
+                   choose_tile(tuple(out_dims)))
     return y, stats
 
 
@@ -221,7 +230,7 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
             taps = [full_taps(k) for k in K]
             be.gather_gemm(dz, None, Cz, _spatial(dz), Cz, in_dims, cfg.stride, tuple(-p for p in cfg.pad), taps,
                            K[1], K[2], wp, Npad, dx, in_dims, cnt, (1, 1, 1), (0, 0, 0), None, ACT_NONE, 0.0, None,
-                           0, choose_tile(in_dims))
+                           0, choose_tile(tuple(in_dims)))
         else:
             wpart = w if (lo == 0 and cnt == w.shape[1]) else w[:, lo:lo + cnt].contiguous()
             wp, Npad = _pack(wpart, 1)
@@ -240,7 +249,18 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias):
     c1 = x1.shape[1]
     Cin = c1 + (x2.shape[1] if x2 is not None else 0)
     if Cin <= 2:
-        return be.small_cin_wgrad(x1, w, dz, cfg.stride, cfg.pad, want_bias)
+        # thin input: im2col columns (k = ci*T + tap) + a 1x1x1 weight gradient on the MFMA path
+        Cout, kcols = w.shape[0], Cin * T
+        if Cout % 32:
+            return be.small_cin_wgrad(x1, w, dz, cfg.stride, cfg.pad, want_bias)
+        kpad = -(-kcols // 32) * 32
+        col = be.im2col(x1, w, _spatial(dz), cfg.stride, cfg.pad, kpad)
+        tmp = torch.empty((Cout, kpad), dtype=w.dtype, device=w.device)
+        db = torch.empty((Cout,), dtype=w.dtype, device=w.device) if want_bias else None
+        one = [full_taps(1)] * 3
+        be.wgrad(dz, Cout, col, kpad, N, _spatial(dz), _spatial(dz), (1, 1, 1), (0, 0, 0), one, 1, 1, tmp, 0,
+                 (kpad, 1, 0), False, db)
+        return tmp[:, :kcols].reshape(w.shape).contiguous(), db
     dw = torch.empty(tuple(w.shape), dtype=w.dtype, device=w.device)
     db = None
     taps = [full_taps(k) for k in K]

@@ -122,6 +122,22 @@ def small_cin_fwd(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
             stats[:, :, 1] += (v.double() ** 2).sum((2, 3, 4))
 
 
+def im2col(x, w, out_dims, stride, pad, Kpad):
+    N, Cin = x.shape[:2]
+    KD, KH, KW = w.shape[2:]
+    T = KD * KH * KW
+    assert Kpad % 4 == 0 and Kpad >= Cin * T
+    col = torch.zeros((N, Kpad) + tuple(out_dims), dtype=x.dtype)
+    for ci in range(Cin):
+        for kd in range(KD):
+            for kh in range(KH):
+                for kw in range(KW):
+                    k = ci * T + (kd * KH + kh) * KW + kw
+                    col[:, k:k + 1] = _gather(x[:, ci:ci + 1], out_dims, stride, tuple(-p for p in pad),
+                                              (kd, kh, kw), tuple(x.shape[2:]))
+    return col.contiguous(memory_format=torch.channels_last_3d)
+
+
 def small_cin_wgrad(x, w, dy, stride, pad, want_bias):
     dw = torch.nn.grad.conv3d_weight(x, w.shape, dy, stride, pad)
     return dw, (dy.sum((0, 2, 3, 4)) if want_bias else None)
