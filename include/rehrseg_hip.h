@@ -67,7 +67,7 @@ typedef struct {
   const float* x1;
   const float* x2;
   int32_t c1, ldx1, ldx2;
-  int32_t N, Di, Hi, Wi, Cin;      /* Cin % 32 == 0, c1 % 32 == 0 */
+  int32_t N, Di, Hi, Wi, Cin;      /* Cin % 16 == 0; c1 % 32 == 0 when x2 is used */
   /* lattice and its map into the source */
   int32_t Ld, Lh, Lw;
   int32_t sd, sh, sw, bd, bh, bw;
@@ -110,9 +110,9 @@ int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);
  * ------------------------------------------------------------------------- */
 typedef struct {
   const float* l;
-  int32_t ldl, Ca;                 /* Ca % 32 == 0 */
+  int32_t ldl, Ca;                 /* Ca % 4 == 0 */
   const float* g;
-  int32_t ldg, Cg;                 /* Cg % 32 == 0 */
+  int32_t ldg, Cg;                 /* Cg % 4 == 0 */
   int32_t N, Ld, Lh, Lw;           /* lattice (= spatial dims of l) */
   int32_t Dg, Hg, Wg;              /* spatial dims of g */
   int32_t sd, sh, sw, bd, bh, bw;
@@ -169,6 +169,18 @@ int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc* d
 int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* d, float* dw,
                                   float* dbias, float* workspace,
                                   int64_t workspace_bytes, void* stream);
+
+/* Direct convolution for Cout <= 4, Cin % 16 == 0, stride 1, kW <= 7 (HBM/VALU
+ * bound): the 1x1x1 segmentation layer (models/seg_model.py:42-44) and sr_head's
+ * 5x5x5 16->num_classes conv (models/seg_model.py:199), with both gradients.
+ * Same descriptor; `y` is the output (forward) or dY (gradients).              */
+int rehr_conv_small_cout_fwd_f32(const rehr_direct_conv_desc* d, void* stream);
+int rehr_conv_small_cout_dgrad_f32(const rehr_direct_conv_desc* d, float* dx,
+                                   void* stream);
+int64_t rehr_conv_small_cout_wgrad_workspace_bytes(const rehr_direct_conv_desc* d);
+int rehr_conv_small_cout_wgrad_f32(const rehr_direct_conv_desc* d, float* dw,
+                                   float* dbias, float* workspace,
+                                   int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * SEGating (models/FLAVR/resnet_3D.py:100-116) and its fused neighbours.

@@ -340,3 +340,353 @@ extern "C" int rehr_im2col_f32(const rehr_direct_conv_desc* dp, float* out, int3
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
+
+// ------------------------------------------------------------------ thin-output convolutions
+// Cout <= 4 (segmentation logits: 1x1x1 seg layer, sr_head's 5x5x5 16->2), stride 1.
+// HBM/VALU bound.  A thread owns 4 consecutive output voxels along W; for every
+// (kd,kh) it loads the row segment it needs once into registers and slides the KW
+// taps over it, with the weights of that (kd,kh) broadcast from LDS.
+namespace {
+
+constexpr int SC_VOX = 4;     // voxels per thread along W
+constexpr int SC_MAXKW = 7;
+constexpr int SC_BIAS_BLOCKS = 1024;
+
+// forward: y[o][co] = b[co] + sum x[o - p + k][ci] * w[co][ci][k]
+template <int CO>
+__global__ __launch_bounds__(256) void small_cout_fwd_kernel(const rehr_direct_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [T][CO][Cin]
+  const int T = d.KD * d.KH * d.KW;
+  for (int i = threadIdx.x; i < CO * d.Cin * T; i += 256) {
+    const int co = i / (d.Cin * T), rem = i - co * d.Cin * T;
+    const int ci = rem / T, t = rem - ci * T;
+    wl[(t * CO + co) * d.Cin + ci] = (co < d.Cout) ? d.w[((int64_t)co * d.Cin + ci) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int wg = (d.Wo + SC_VOX - 1) / SC_VOX;
+  const int64_t groups = (int64_t)d.N * d.Do * d.Ho * wg;
+  for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
+    const int gw = (int)(gidx % wg);
+    int64_t r = gidx / wg;
+    const int oh = (int)(r % d.Ho); r /= d.Ho;
+    const int od = (int)(r % d.Do);
+    const int n = (int)(r / d.Do);
+    const int ow0 = gw * SC_VOX;
+    float acc[SC_VOX][CO];
+#pragma unroll
+    for (int v = 0; v < SC_VOX; ++v)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[v][c] = (d.bias && c < d.Cout) ? d.bias[c] : 0.f;
+    const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
+    for (int kd = 0; kd < d.KD; ++kd) {
+      const int id = od - d.pd + kd;
+      if ((unsigned)id >= (unsigned)d.Di) continue;
+      for (int kh = 0; kh < d.KH; ++kh) {
+        const int ih = oh - d.ph + kh;
+        if ((unsigned)ih >= (unsigned)d.Hi) continue;
+        const float* xr = xn + ((int64_t)id * d.Hi + ih) * d.Wi * d.ldx;
+        const float* wr = wl + (kd * d.KH + kh) * d.KW * CO * d.Cin;
+        for (int c4 = 0; c4 < d.Cin; c4 += 4) {
+          f32x4 seg[SC_VOX + SC_MAXKW - 1];
+#pragma unroll
+          for (int j = 0; j < SC_VOX + SC_MAXKW - 1; ++j) {
+            const int iw = ow0 - d.pw + j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < SC_VOX + d.KW - 1 && (unsigned)iw < (unsigned)d.Wi)
+              v = *reinterpret_cast<const f32x4*>(xr + (int64_t)iw * d.ldx + c4);
+            seg[j] = v;
+          }
+#pragma unroll
+          for (int kw = 0; kw < SC_MAXKW; ++kw) {
+            if (kw < d.KW) {
+#pragma unroll
+              for (int c = 0; c < CO; ++c) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (kw * CO + c) * d.Cin + c4);
+#pragma unroll
+                for (int v = 0; v < SC_VOX; ++v) {
+                  const f32x4 xv = seg[v + kw];
+                  acc[v][c] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    float* yo = d.y + ((((int64_t)n * d.Do + od) * d.Ho + oh) * d.Wo + ow0) * d.ldy;
+#pragma unroll
+    for (int v = 0; v < SC_VOX; ++v)
+      if (ow0 + v < d.Wo)
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+          if (c < d.Cout) yo[(int64_t)v * d.ldy + c] = apply_act(acc[v][c], d.act, d.slope);
+  }
+}
+
+// input gradient: dx[i][ci] = sum_{k,co} dy[i + p - k][co] * w[co][ci][k]   (stride 1)
+template <int CO>
+__global__ __launch_bounds__(256) void small_cout_dgrad_kernel(const rehr_direct_conv_desc d,
+                                                               float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [T][CO][Cin]
+  const int T = d.KD * d.KH * d.KW;
+  for (int i = threadIdx.x; i < CO * d.Cin * T; i += 256) {
+    const int co = i / (d.Cin * T), rem = i - co * d.Cin * T;
+    const int ci = rem / T, t = rem - ci * T;
+    wl[(t * CO + co) * d.Cin + ci] = (co < d.Cout) ? d.w[((int64_t)co * d.Cin + ci) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int wg = (d.Wi + SC_VOX - 1) / SC_VOX;
+  const int c16n = d.Cin / 16;
+  const int64_t groups = (int64_t)d.N * d.Di * d.Hi * wg * c16n;
+  for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
+    const int gw = (int)(gidx % wg);
+    int64_t r = gidx / wg;
+    const int cb = (int)(r % c16n) * 16; r /= c16n;
+    const int ih = (int)(r % d.Hi); r /= d.Hi;
+    const int id = (int)(r % d.Di);
+    const int n = (int)(r / d.Di);
+    const int iw0 = gw * SC_VOX;
+    f32x4 acc[SC_VOX][4];
+#pragma unroll
+    for (int v = 0; v < SC_VOX; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[v][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* yn = d.y + (int64_t)n * d.Do * d.Ho * d.Wo * d.ldy;
+    for (int kd = 0; kd < d.KD; ++kd) {
+      const int od = id + d.pd - kd;
+      if ((unsigned)od >= (unsigned)d.Do) continue;
+      for (int kh = 0; kh < d.KH; ++kh) {
+        const int oh = ih + d.ph - kh;
+        if ((unsigned)oh >= (unsigned)d.Ho) continue;
+        const float* yr = yn + ((int64_t)od * d.Ho + oh) * d.Wo * d.ldy;
+        const float* wr = wl + (kd * d.KH + kh) * d.KW * CO * d.Cin;
+        // dy row segment: positions iw0 + p - (KW-1) .. iw0 + p + SC_VOX - 1
+        float seg[SC_VOX + SC_MAXKW - 1][CO];
+#pragma unroll
+        for (int j = 0; j < SC_VOX + SC_MAXKW - 1; ++j) {
+          const int ow = iw0 + d.pw - (d.KW - 1) + j;
+          const bool ok = j < SC_VOX + d.KW - 1 && (unsigned)ow < (unsigned)d.Wo;
+#pragma unroll
+          for (int c = 0; c < CO; ++c) seg[j][c] = (ok && c < d.Cout) ? yr[(int64_t)ow * d.ldy + c] : 0.f;
+        }
+#pragma unroll
+        for (int kw = 0; kw < SC_MAXKW; ++kw) {
+          if (kw < d.KW) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (kw * CO + c) * d.Cin + cb + q * 4);
+#pragma unroll
+                for (int v = 0; v < SC_VOX; ++v) acc[v][q] += wv * seg[v + (d.KW - 1) - kw][c];
+              }
+            }
+          }
+        }
+      }
+    }
+    float* xo = dx + ((((int64_t)n * d.Di + id) * d.Hi + ih) * d.Wi + iw0) * d.ldx + cb;
+#pragma unroll
+    for (int v = 0; v < SC_VOX; ++v)
+      if (iw0 + v < d.Wi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xo + (int64_t)v * d.ldx + q * 4) = acc[v][q];
+  }
+}
+
+// weight gradient: dw[co][ci][k] = sum dy[o][co] * x[o - p + k][ci].  A block owns one
+// (kd,kh) and a 4-channel slice of ci; a thread owns output positions along W with lanes
+// on consecutive w (coalesced) and walks a strip of (n,d,h) rows, keeping KW*4*CO sums.
+template <int CO>
+__global__ __launch_bounds__(256) void small_cout_wgrad_kernel(const rehr_direct_conv_desc d,
+                                                               float* __restrict__ slab, int rows_per_block) {
+  __shared__ float red[256];
+  const int c4n = d.Cin / 4;
+  int b = blockIdx.x;
+  const int c4 = (b % c4n) * 4; b /= c4n;
+  const int kh = b % d.KH; b /= d.KH;
+  const int kd = b % d.KD; b /= d.KD;
+  const int strip = b;  // strip of rows
+  const int64_t nrows = (int64_t)d.N * d.Do * d.Ho;
+  const int64_t row0 = (int64_t)strip * rows_per_block;
+  float acc[SC_MAXKW][4][CO];
+#pragma unroll
+  for (int kw = 0; kw < SC_MAXKW; ++kw)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[kw][e][c] = 0.f;
+  for (int rr = 0; rr < rows_per_block; ++rr) {
+    const int64_t row = row0 + rr;
+    if (row >= nrows) break;
+    const int oh = (int)(row % d.Ho);
+    const int64_t r2 = row / d.Ho;
+    const int od = (int)(r2 % d.Do);
+    const int n = (int)(r2 / d.Do);
+    const int id = od - d.pd + kd, ih = oh - d.ph + kh;
+    if ((unsigned)id >= (unsigned)d.Di || (unsigned)ih >= (unsigned)d.Hi) continue;
+    const float* yr = d.y + (((int64_t)n * d.Do + od) * d.Ho + oh) * d.Wo * d.ldy;
+    const float* xr = d.x + (((int64_t)n * d.Di + id) * d.Hi + ih) * d.Wi * d.ldx + c4;
+    for (int ow = threadIdx.x; ow < d.Wo; ow += 256) {
+      float dyv[CO];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) dyv[c] = (c < d.Cout) ? yr[(int64_t)ow * d.ldy + c] : 0.f;
+#pragma unroll
+      for (int kw = 0; kw < SC_MAXKW; ++kw) {
+        const int iw = ow - d.pw + kw;
+        if (kw < d.KW && (unsigned)iw < (unsigned)d.Wi) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + (int64_t)iw * d.ldx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) acc[kw][e][c] += xv[e] * dyv[c];
+        }
+      }
+    }
+  }
+  // block reduction of KW*4*CO sums -> slab[strip][co][ci][tap]
+  const int T = d.KD * d.KH * d.KW;
+  float* sb = slab + (int64_t)strip * d.Cout * d.Cin * T;
+#pragma unroll
+  for (int kw = 0; kw < SC_MAXKW; ++kw) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        if (kw < d.KW && c < d.Cout) {  // block-uniform
+          float v = wave_sum(acc[kw][e][c]);
+          __syncthreads();
+          if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+          __syncthreads();
+          if (threadIdx.x == 0)
+            sb[((int64_t)c * d.Cin + c4 + e) * T + (kd * d.KH + kh) * d.KW + kw] = red[0] + red[1] + red[2] + red[3];
+        }
+      }
+    }
+  }
+}
+
+// partial[b][c] = sum over the block's voxels of dy[.][c]
+__global__ __launch_bounds__(256) void thin_bias_partial_kernel(const float* __restrict__ dy, int ld, int C,
+                                                                int64_t rows, float* __restrict__ partial) {
+  __shared__ float red[4][4];
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256)
+    for (int c = 0; c < C; ++c) a[c] += dy[r * ld + c];
+  for (int c = 0; c < 4; ++c) {
+    const float v = wave_sum(a[c]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < C)
+    partial[(int64_t)blockIdx.x * 4 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void small_cout_wgrad_reduce_kernel(const float* __restrict__ slab, int strips, int64_t nw,
+                                               float* __restrict__ dw, const float* __restrict__ bpart,
+                                               int bblocks, int C, float* __restrict__ dbias) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < strips; ++k) s += slab[(int64_t)k * nw + i];
+    dw[i] = s;
+  }
+  if (dbias != nullptr && blockIdx.x == 0 && threadIdx.x < C) {
+    float s = 0.f;
+    for (int k = 0; k < bblocks; ++k) s += bpart[(int64_t)k * 4 + threadIdx.x];
+    dbias[threadIdx.x] = s;
+  }
+}
+
+bool small_cout_ok(const rehr_direct_conv_desc& d) {
+  if (!d.x || !d.w || !d.y) return false;
+  if (d.Cout < 1 || d.Cout > 4 || d.Cin < 16 || d.Cin % 16) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
+  if (d.KD < 1 || d.KH < 1 || d.KW < 1 || d.KW > SC_MAXKW) return false;
+  if (d.ldx % 4 || (((uintptr_t)d.x) & 15)) return false;
+  if (d.N < 1) return false;
+  if (d.Di + 2 * d.pd - d.KD + 1 != d.Do || d.Hi + 2 * d.ph - d.KH + 1 != d.Ho || d.Wi + 2 * d.pw - d.KW + 1 != d.Wo)
+    return false;
+  return true;
+}
+int sc_strips(const rehr_direct_conv_desc& d, int* rpb) {
+  const int64_t nrows = (int64_t)d.N * d.Do * d.Ho;
+  const int64_t per_strip_blocks = (int64_t)d.KD * d.KH * (d.Cin / 4);
+  int64_t strips = (4096 + per_strip_blocks - 1) / per_strip_blocks;
+  if (strips > nrows) strips = nrows;
+  if (strips < 1) strips = 1;
+  int64_t r = (nrows + strips - 1) / strips;
+  strips = (nrows + r - 1) / r;
+  *rpb = (int)r;
+  return (int)strips;
+}
+}  // namespace
+
+extern "C" int rehr_conv_small_cout_fwd_f32(const rehr_direct_conv_desc* dp, void* stream) {
+  if (!dp || !small_cout_ok(*dp)) return REHR_EINVAL;
+  const rehr_direct_conv_desc& d = *dp;
+  const int T = d.KD * d.KH * d.KW;
+  const int CO = d.Cout <= 2 ? 2 : 4;
+  const size_t smem = (size_t)T * CO * d.Cin * sizeof(float);
+  if (smem > 64 * 1024) return REHR_ENOSUP;
+  const int64_t groups = (int64_t)d.N * d.Do * d.Ho * ((d.Wo + SC_VOX - 1) / SC_VOX);
+  int64_t blocks = (groups + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (CO == 2)
+    hipLaunchKernelGGL(small_cout_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(small_cout_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, d);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_conv_small_cout_dgrad_f32(const rehr_direct_conv_desc* dp, float* dx, void* stream) {
+  if (!dp || !small_cout_ok(*dp) || !dx || (((uintptr_t)dx) & 15)) return REHR_EINVAL;
+  const rehr_direct_conv_desc& d = *dp;
+  const int T = d.KD * d.KH * d.KW;
+  const int CO = d.Cout <= 2 ? 2 : 4;
+  const size_t smem = (size_t)T * CO * d.Cin * sizeof(float);
+  if (smem > 64 * 1024) return REHR_ENOSUP;
+  const int64_t groups = (int64_t)d.N * d.Di * d.Hi * ((d.Wi + SC_VOX - 1) / SC_VOX) * (d.Cin / 16);
+  int64_t blocks = (groups + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (CO == 2)
+    hipLaunchKernelGGL(small_cout_dgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, d, dx);
+  else
+    hipLaunchKernelGGL(small_cout_dgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, d, dx);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int64_t rehr_conv_small_cout_wgrad_workspace_bytes(const rehr_direct_conv_desc* dp) {
+  if (!dp || !small_cout_ok(*dp)) return REHR_EINVAL;
+  int rpb;
+  const int strips = sc_strips(*dp, &rpb);
+  return ((int64_t)strips * dp->Cout * dp->Cin * dp->KD * dp->KH * dp->KW + SC_BIAS_BLOCKS * 4) * sizeof(float);
+}
+
+extern "C" int rehr_conv_small_cout_wgrad_f32(const rehr_direct_conv_desc* dp, float* dw, float* dbias,
+                                              float* workspace, int64_t workspace_bytes, void* stream) {
+  if (!dp || !small_cout_ok(*dp) || !dw || !workspace) return REHR_EINVAL;
+  const rehr_direct_conv_desc& d = *dp;
+  int rpb;
+  const int strips = sc_strips(d, &rpb);
+  const int64_t nw = (int64_t)d.Cout * d.Cin * d.KD * d.KH * d.KW;
+  if (workspace_bytes < ((int64_t)strips * nw + SC_BIAS_BLOCKS * 4) * (int64_t)sizeof(float)) return REHR_EINVAL;
+  float* bpart = workspace + (int64_t)strips * nw;
+  const int CO = d.Cout <= 2 ? 2 : 4;
+  const int64_t blocks = (int64_t)strips * d.KD * d.KH * (d.Cin / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, (size_t)strips * nw * sizeof(float), st) != hipSuccess) return REHR_EHIP;
+  if (CO == 2)
+    hipLaunchKernelGGL(small_cout_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, d, workspace, rpb);
+  else
+    hipLaunchKernelGGL(small_cout_wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, d, workspace, rpb);
+  if (dbias != nullptr)
+    hipLaunchKernelGGL(thin_bias_partial_kernel, dim3(SC_BIAS_BLOCKS), dim3(256), 0, st, d.y, d.ldy, d.Cout,
+                       (int64_t)d.N * d.Do * d.Ho * d.Wo, bpart);
+  hipLaunchKernelGGL(small_cout_wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, workspace,
+                     strips, nw, dw, bpart, SC_BIAS_BLOCKS, d.Cout, dbias);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}

@@ -191,13 +191,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
     const uint32_t ldb = (uint32_t)(first ? d.ldx1 : d.ldx2) * 4u;
     const uint32_t cb = (uint32_t)((first ? cc : cc - d.c1) + q * 4) * 4u;
     const uint32_t oob = first ? nrec1 : nrec2;
+    const bool kok = (cc + q * 4) < d.Cin;  // Cin % 16 == 0: the last 32-chunk may be half empty
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int id = sd0[i] + dd, ih = sh0[i] + dh, iw = sw0[i] + dw;
       const bool inb = ((unsigned)id < (unsigned)d.Di) & ((unsigned)ih < (unsigned)d.Hi) &
                        ((unsigned)iw < (unsigned)d.Wi);  // bitwise: no short-circuit branches
       const uint32_t lin = (uint32_t)(rowvox[i] + tapvox) * ldb + cb;
-      const uint32_t off = inb ? lin : oob;
+      const uint32_t off = (inb & kok) ? lin : oob;
       ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
     const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW +
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
       rb[i] = __builtin_bit_cast(
-          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (uint32_t)(32 * i) * d.Cin * 4u, 0, 0));
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                     rsw, kok ? woff + (uint32_t)(32 * i) * d.Cin * 4u : nrecw, 0, 0));
     // advance iterator (scalar)
     ++jw;
     const bool cw = jw > jw1;
@@ -339,7 +341,8 @@ extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* strea
   if (dp == nullptr) return REHR_EINVAL;
   const rehr_gather_gemm_desc& d = *dp;
   if (!d.x1 || !d.wp || !d.y) return REHR_EINVAL;
-  if (d.N < 1 || d.Cin < 32 || d.Cin % 32 || d.c1 % 32 || d.c1 < 0 || d.c1 > d.Cin) return REHR_EINVAL;
+  if (d.N < 1 || d.Cin < 16 || d.Cin % 16 || d.c1 < 0 || d.c1 > d.Cin) return REHR_EINVAL;
+  if (d.c1 < d.Cin && d.c1 % 32) return REHR_EINVAL;  // a virtual concat splits on a chunk boundary
   if (d.c1 < d.Cin && !d.x2) return REHR_EINVAL;
   if (d.c1 == 0) return REHR_EINVAL;
   if (d.ldx1 % 4 || (d.x2 && d.ldx2 % 4)) return REHR_EINVAL;
@@ -373,7 +376,7 @@ extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* strea
     p.tiles_w = (d.Lw + d.tile_w - 1) / d.tile_w;
     p.m_tiles = p.tiles_d * p.tiles_h * p.tiles_w;
   }
-  p.kchunks = d.Cin / 32;
+  p.kchunks = (d.Cin + 31) / 32;
   {
     // buffer-addressed operands: 32-bit byte offsets per sample / per weight panel
     const int64_t kd_max = d.td.k0 + (int64_t)d.td.ks * (d.td.count - 1);

@@ -294,13 +294,13 @@ __global__ void wgrad_reduce_kernel(const WGParams p) {
   }
 }
 
-int tile_for(int c) { return (c % 128 == 0) ? 128 : ((c % 64 == 0) ? 64 : 32); }
+int tile_for(int c) { return (c % 128 == 0) ? 128 : ((c % 64 == 0) ? 64 : 32); }  // c % 32 != 0 -> masked 32-tiles
 int bkv_for(int t) { return t == 128 ? 32 : 64; }
 
 // 0 ok, else REHR_* code
 int plan(const rehr_wgrad_desc& d, WGParams& p) {
   if (!d.l || !d.g || !d.dst) return REHR_EINVAL;
-  if (d.Ca < 32 || d.Ca % 32 || d.Cg < 32 || d.Cg % 32) return REHR_EINVAL;
+  if (d.Ca < 4 || d.Ca % 4 || d.Cg < 4 || d.Cg % 4) return REHR_EINVAL;  // tiles are padded, columns masked
   if (d.ldl % 4 || d.ldg % 4) return REHR_EINVAL;
   if (((uintptr_t)d.l | (uintptr_t)d.g) & 15) return REHR_EINVAL;
   if (d.N < 1 || d.Ld < 1 || d.Lh < 1 || d.Lw < 1) return REHR_EINVAL;
@@ -328,6 +328,21 @@ int plan(const rehr_wgrad_desc& d, WGParams& p) {
   if (want > max_by_k) want = max_by_k;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
+  {
+    // All blocks take the same time and 512 are resident at once (256 CUs x 2): pick the
+    // split count near `want` whose last round of blocks is fullest (tail effect).
+    int64_t best = want;
+    double best_eff = 0.0;
+    const int64_t lo = want > 2 ? want - want / 3 : 1;
+    int64_t hi = want + want / 2 + 1;
+    if (hi > max_by_k) hi = max_by_k > want ? max_by_k : want;
+    for (int64_t s = lo; s <= hi; ++s) {
+      const double rounds = (double)(tiles * s) / 512.0;
+      const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    }
+    want = best;
+  }
   int64_t per = (p.kv_total + want - 1) / want;
   per = (per + bkv - 1) / bkv * bkv;
   if ((int64_t)per * d.ldl * 4 >= (1ll << 32) - 64) return REHR_ENOSUP;

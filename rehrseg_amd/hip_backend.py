@@ -218,6 +218,36 @@ def small_cin_wgrad(x, w, dy, stride, pad, want_bias):
     return dw, db
 
 
+def small_cout_fwd(x, w, bias, y, pad, act, slope):
+    _chk_dev(x, w, bias, y)
+    d = _direct_desc(x, w.contiguous(), bias, y, (1, 1, 1), pad, act, slope, None, 0)
+    L.check(L.load().rehr_conv_small_cout_fwd_f32(C.byref(d), _stream()), "rehr_conv_small_cout_fwd_f32")
+
+
+def small_cout_dgrad(dy, w, x_shape, pad):
+    _chk_dev(dy, w)
+    dx = new_act(*x_shape, like=dy)
+    d = _direct_desc(dx, w.contiguous(), None, dy, (1, 1, 1), pad, 0, 0.0, None, 0)
+    L.check(L.load().rehr_conv_small_cout_dgrad_f32(C.byref(d), _ptr(dx), _stream()),
+            "rehr_conv_small_cout_dgrad_f32")
+    return dx
+
+
+def small_cout_wgrad(x, w, dy, pad, want_bias):
+    _chk_dev(x, w, dy)
+    d = _direct_desc(x, w.contiguous(), None, dy, (1, 1, 1), pad, 0, 0.0, None, 0)
+    lib = L.load()
+    nbytes = lib.rehr_conv_small_cout_wgrad_workspace_bytes(C.byref(d))
+    if nbytes < 0:
+        L.check(int(nbytes), "rehr_conv_small_cout_wgrad_workspace_bytes")
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+    db = torch.empty(w.shape[0], dtype=torch.float32, device=x.device) if want_bias else None
+    L.check(lib.rehr_conv_small_cout_wgrad_f32(C.byref(d), _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream()),
+            "rehr_conv_small_cout_wgrad_f32")
+    return dw, db
+
+
 def se_gate_fwd(stats, w, b, N, Cc, S):
     _chk_dev(stats, w, b)
     gate = torch.empty((N, Cc), dtype=torch.float32, device=stats.device)

@@ -85,6 +85,10 @@ PROTOTYPES = {
     "rehr_im2col_f32": (C.c_int, [_P_DC, _vp, _i32, _vp]),
     "rehr_conv_small_cin_wgrad_workspace_bytes": (_i64, [_P_DC]),
     "rehr_conv_small_cin_wgrad_f32": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),
+    "rehr_conv_small_cout_fwd_f32": (C.c_int, [_P_DC, _vp]),
+    "rehr_conv_small_cout_dgrad_f32": (C.c_int, [_P_DC, _vp, _vp]),
+    "rehr_conv_small_cout_wgrad_workspace_bytes": (_i64, [_P_DC]),
+    "rehr_conv_small_cout_wgrad_f32": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),
     "rehr_se_gate_fwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),
     "rehr_scale_res_act_fwd_f32": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp]),
     "rehr_scale_res_act_bwd_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp,

@@ -174,6 +174,12 @@ def _has_empty_phase(K, stride, pad):
     return any(phase_taps(K[a], stride[a], pad[a], ph) is None for a in range(3) for ph in range(stride[a]))
 
 
+def _thin_out(w, cfg: ConvCfg, has_x2):
+    """Segmentation-logit convs (Cout <= 4, stride 1): direct HBM-bound kernels, not MFMA tiles."""
+    return (not cfg.transposed and not has_x2 and w.shape[0] <= 4 and w.shape[1] % 16 == 0 and
+            cfg.stride == (1, 1, 1) and w.shape[4] <= 7)
+
+
 def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     """Returns (y, stats).  x2 = second half of a virtual channel concat."""
     be = get_backend()
@@ -193,6 +199,12 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
         y = be.new_act(N, Cout, *out_dims, like=x1)
         be.small_cin_fwd(x1, w, bias, y, cfg.stride, cfg.pad, act, slope, stats, stats_mode)
         return y, stats
+    if _thin_out(w, cfg, x2 is not None):
+        if stats_mode:
+            raise NotImplementedError("statistics epilogue on a thin-output conv")
+        y = be.new_act(N, Cout, *out_dims, like=x1)
+        be.small_cout_fwd(x1, w, bias, y, cfg.pad, act, slope)
+        return y, None
     if cfg.transposed:
         empty = _has_empty_phase(K, cfg.stride, cfg.pad)
         if empty and bias is not None:
@@ -217,6 +229,8 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
     N = dz.shape[0]
     K = tuple(w.shape[2:])
     Cz = dz.shape[1]
+    if _thin_out(w, cfg, c2 > 0):
+        return (be.small_cout_dgrad(dz, w, (N, c1) + tuple(in_dims), cfg.pad) if need1 else None), None
     out = []
     for (lo, cnt, need) in ((0, c1, need1), (c1, c2, need2)):
         if cnt == 0 or not need:
@@ -261,6 +275,8 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias):
         be.wgrad(dz, Cout, col, kpad, N, _spatial(dz), _spatial(dz), (1, 1, 1), (0, 0, 0), one, 1, 1, tmp, 0,
                  (kpad, 1, 0), False, db)
         return tmp[:, :kcols].reshape(w.shape).contiguous(), db
+    if _thin_out(w, cfg, x2 is not None):
+        return be.small_cout_wgrad(x1, w, dz, cfg.pad, want_bias)
     dw = torch.empty(tuple(w.shape), dtype=w.dtype, device=w.device)
     db = None
     taps = [full_taps(k) for k in K]

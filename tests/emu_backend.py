@@ -58,7 +58,7 @@ def _gather(X, lattice, s, b, off, dims):
 
 def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
                 os_, ob, bias, act, slope, stats, stats_mode, tile):
-    assert Cin % 32 == 0 and c1 % 32 == 0 and Npad % 32 == 0 and wp.shape[1] == Npad and wp.shape[2] == Cin
+    assert Cin % 16 == 0 and (x2 is None or c1 % 32 == 0) and Npad % 32 == 0 and wp.shape[1] == Npad and wp.shape[2] == Cin
     assert tile == (0, 0, 0) or tile[0] * tile[1] * tile[2] == 128
     assert tuple(x1.shape[2:]) == tuple(src_dims) and tuple(y.shape[2:]) == tuple(y_dims)
     X = torch.cat([x1, x2], 1) if x2 is not None else x1
@@ -88,7 +88,7 @@ def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
 
 
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):
-    assert Ca % 32 == 0 and Cg % 32 == 0 and tuple(l.shape[2:]) == tuple(lattice)
+    assert Ca % 4 == 0 and Cg % 4 == 0 and tuple(l.shape[2:]) == tuple(lattice)
     flat = dst.view(-1)
     (cd, od0, ods, kd0, kds), (ch, oh0, ohs, kh0, khs), (cw, ow0, ows, kw0, kws) = taps
     sa, sc, st = dst_strides
@@ -141,6 +141,19 @@ def im2col(x, w, out_dims, stride, pad, Kpad):
 def small_cin_wgrad(x, w, dy, stride, pad, want_bias):
     dw = torch.nn.grad.conv3d_weight(x, w.shape, dy, stride, pad)
     return dw, (dy.sum((0, 2, 3, 4)) if want_bias else None)
+
+
+def small_cout_fwd(x, w, bias, y, pad, act, slope):
+    assert w.shape[0] <= 4 and x.shape[1] % 16 == 0
+    y.copy_(_act(torch.nn.functional.conv3d(x, w, bias, 1, pad), act, slope))
+
+
+def small_cout_dgrad(dy, w, x_shape, pad):
+    return torch.nn.grad.conv3d_input(x_shape, w, dy, 1, pad).contiguous(memory_format=torch.channels_last_3d)
+
+
+def small_cout_wgrad(x, w, dy, pad, want_bias):
+    return torch.nn.grad.conv3d_weight(x, w.shape, dy, 1, pad), (dy.sum((0, 2, 3, 4)) if want_bias else None)
 
 
 def se_gate_fwd(stats, w, b, N, Cc, S):

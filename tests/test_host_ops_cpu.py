@@ -158,6 +158,22 @@ def test_upsample_depth(emu, Di, scale):
     _cmp(torch.autograd.grad(y, x, g)[0], torch.autograd.grad(ref, x, g)[0], 1e-6)
 
 
+@pytest.mark.parametrize("Cin,Cout,K,pad", [(32, 2, (1, 1, 1), 0), (16, 2, (5, 5, 5), 2), (32, 16, (3, 3, 3), 1),
+                                            (64, 4, (1, 7, 7), (0, 3, 3))])
+def test_thin_output_and_half_chunk_convs(emu, Cin, Cout, K, pad):
+    x = _rand(2, Cin, 4, 5, 9).requires_grad_()
+    w = _rand(Cout, Cin, *K).requires_grad_()
+    b = _rand(Cout).requires_grad_()
+    y = ops.fused_conv3d(x, w, b, 1, pad, act=ops.ACT_RELU if Cout == 16 else ops.ACT_NONE)
+    ref = F.conv3d(x, w, b, 1, pad)
+    if Cout == 16:
+        ref = torch.relu(ref)
+    _cmp(y, ref)
+    g = torch.randn_like(ref)
+    for a, e in zip(torch.autograd.grad(y, (x, w, b), g), torch.autograd.grad(ref, (x, w, b), g)):
+        _cmp(a, e)
+
+
 def test_choose_tile():
     assert ops.choose_tile((128, 64, 64))[0] * ops.choose_tile((128, 64, 64))[1] * ops.choose_tile((128, 64, 64))[2] == 128
     assert ops.choose_tile((4, 12, 12)) == (0, 0, 0)

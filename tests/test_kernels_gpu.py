@@ -155,6 +155,19 @@ def test_thin_input_conv_instnorm():
          [x, w, b, ga, be], [False, True, False, True, True])
 
 
+@pytest.mark.parametrize("Cin,Cout,K,pad,dims", [(32, 2, (1, 1, 1), (0, 0, 0), (2, 5, 9, 13)),
+                                                 (16, 2, (5, 5, 5), (2, 2, 2), (2, 6, 9, 13)),
+                                                 (32, 16, (3, 3, 3), (1, 1, 1), (1, 5, 9, 12)),
+                                                 (64, 4, (1, 7, 7), (0, 3, 3), (1, 1, 20, 22))])
+def test_thin_output_and_half_chunk_convs(Cin, Cout, K, pad, dims):
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=40)
+    w = _mk(Cout, Cin, *K, seed=41) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=42)
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, pad), lambda x, w, b: F.conv3d(x, w, b, 1, pad),
+         [x, w, b], [True, True, True])
+
+
 @pytest.mark.parametrize("Di,scale", [(5, 4), (7, 2), (1, 3)])
 def test_upsample_depth(Di, scale):
     x = _mk(2, 32, Di, 6, 7, seed=32)
