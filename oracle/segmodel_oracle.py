@@ -1,0 +1,103 @@
+"""Functional CPU restatement of SegModel (TEST INFRASTRUCTURE) -- PARITY UNPINNED.
+
+In-reference parts followed: models/seg_model.py:26-58 (MyUnetDecoder.forward),
+:174-210 (SegModel: sr_head, depth-only trilinear upsample align_corners=True).
+The encoder/decoder bases come from dynamic_network_architectures==0.3.1
+(requirements.txt:20; call sites models/seg_model.py:9-10,153,174-191,
+train_all.py:474-493), which is absent offline and not vendored; its published
+block semantics are restated: per stage n_conv x [Conv3d(k, pad=(k-1)//2, stride on
+the first conv) -> InstanceNorm3d(eps, affine) -> LeakyReLU(0.01)], decoder stage =
+ConvTranspose3d(kernel=stride) -> cat(skip) -> conv blocks, 1x1x1 seg layers.
+The reference ships no test or fixture for this boundary, so nothing can pin it.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _t(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * 3
+
+
+def _cna(sd, p, x, k, stride, eps, slope):
+    k = _t(k)
+    y = F.conv3d(x, sd[p + "conv.weight"], sd.get(p + "conv.bias"), _t(stride), tuple((i - 1) // 2 for i in k))
+    y = F.instance_norm(y, weight=sd[p + "norm.weight"], bias=sd[p + "norm.bias"], eps=eps)
+    return F.leaky_relu(y, slope)
+
+
+def seg_model(sd, x, cfg, return_features=False):
+    """cfg: dict(n_stages, features_per_stage, kernel_sizes, strides, n_conv_per_stage,
+    n_conv_per_stage_decoder, num_classes, upscale, eps, slope, deep_supervision)."""
+    eps, slope = cfg.get("eps", 1e-5), cfg.get("slope", 0.01)
+    n = cfg["n_stages"]
+    skips = []
+    for s in range(n):
+        for i in range(cfg["n_conv_per_stage"][s]):
+            x = _cna(sd, f"encoder.stages.{s}.0.convs.{i}.", x, cfg["kernel_sizes"][s],
+                     cfg["strides"][s] if i == 0 else 1, eps, slope)
+        skips.append(x)
+    lres, segs, feats = skips[-1], [], None
+    for s in range(n - 1):
+        st = _t(cfg["strides"][-(s + 1)])
+        up = F.conv_transpose3d(lres, sd[f"decoder.transpconvs.{s}.weight"], sd.get(f"decoder.transpconvs.{s}.bias"), st)
+        x = torch.cat((up, skips[-(s + 2)]), 1)
+        for i in range(cfg["n_conv_per_stage_decoder"][s]):
+            x = _cna(sd, f"decoder.stages.{s}.convs.{i}.", x, cfg["kernel_sizes"][-(s + 2)], 1, eps, slope)
+        if s == n - 2:
+            feats = x
+        if cfg.get("deep_supervision", False):
+            segs.append(F.conv3d(x, sd[f"decoder.seg_layers.{s}.weight"], sd[f"decoder.seg_layers.{s}.bias"]))
+        elif s == n - 2:
+            segs.append(F.conv3d(x, sd[f"decoder.seg_layers.{n - 2}.weight"], sd[f"decoder.seg_layers.{n - 2}.bias"]))
+        lres = x
+    segs = segs[::-1]
+    out = segs if cfg.get("deep_supervision", False) else segs[0]
+    up = F.interpolate(feats, scale_factor=(cfg["upscale"], 1, 1), mode="trilinear", align_corners=True)
+    up = torch.relu(F.conv3d(up, sd["sr_head.0.weight"], sd["sr_head.0.bias"], 1, 1))
+    up = F.conv3d(up, sd["sr_head.2.weight"], sd["sr_head.2.bias"], 1, 2)
+    if return_features:
+        return out, up, skips
+    return out, up
+
+
+def segmodel_shapes(cfg, input_channels=1):
+    """Parameter name -> shape, primary keys only (no all_modules / decoder.encoder aliases)."""
+    s = {}
+    cin = input_channels
+    n = cfg["n_stages"]
+    f = cfg["features_per_stage"]
+    for st in range(n):
+        for i in range(cfg["n_conv_per_stage"][st]):
+            p = f"encoder.stages.{st}.0.convs.{i}."
+            s[p + "conv.weight"] = (f[st], cin if i == 0 else f[st]) + _t(cfg["kernel_sizes"][st])
+            s[p + "conv.bias"] = (f[st],)
+            s[p + "norm.weight"] = (f[st],)
+            s[p + "norm.bias"] = (f[st],)
+        cin = f[st]
+    for st in range(n - 1):
+        below, skip = f[-(st + 1)], f[-(st + 2)]
+        s[f"decoder.transpconvs.{st}.weight"] = (below, skip) + _t(cfg["strides"][-(st + 1)])
+        s[f"decoder.transpconvs.{st}.bias"] = (skip,)
+        for i in range(cfg["n_conv_per_stage_decoder"][st]):
+            p = f"decoder.stages.{st}.convs.{i}."
+            s[p + "conv.weight"] = (skip, 2 * skip if i == 0 else skip) + _t(cfg["kernel_sizes"][-(st + 2)])
+            s[p + "conv.bias"] = (skip,)
+            s[p + "norm.weight"] = (skip,)
+            s[p + "norm.bias"] = (skip,)
+        s[f"decoder.seg_layers.{st}.weight"] = (cfg["num_classes"], skip, 1, 1, 1)
+        s[f"decoder.seg_layers.{st}.bias"] = (cfg["num_classes"],)
+    s["sr_head.0.weight"] = (16, 32, 3, 3, 3)
+    s["sr_head.0.bias"] = (16,)
+    s["sr_head.2.weight"] = (cfg["num_classes"], 16, 5, 5, 5)
+    s["sr_head.2.bias"] = (cfg["num_classes"],)
+    return s
+
+
+ISO_PLAN = dict(n_stages=6, features_per_stage=[32, 64, 128, 256, 320, 320], kernel_sizes=[[3, 3, 3]] * 6,
+                strides=[[1, 1, 1]] + [[2, 2, 2]] * 5, n_conv_per_stage=[2] * 6, n_conv_per_stage_decoder=[2] * 5,
+                num_classes=2, upscale=4)
+# distillation-compatible plan (stage-1 stride (1,2,2); DS scale table utils/seg_utils.py:364)
+ANISO_PLAN = dict(n_stages=6, features_per_stage=[32, 64, 128, 256, 320, 320],
+                  kernel_sizes=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+                  strides=[[1, 1, 1], [1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2]],
+                  n_conv_per_stage=[2] * 6, n_conv_per_stage_decoder=[2] * 5, num_classes=2, upscale=4)
