@@ -123,16 +123,16 @@ __global__ void scale_res_act_fwd_kernel(const float* __restrict__ x, int ldx,
 template <int NQ, typename F>
 __device__ __forceinline__ void column_reduce(int64_t row_begin, int64_t row_end, int C, double* out,
                                               int out_stride, F body) {
-  __shared__ float red[EW_THREADS * NQ * 4];
+  __shared__ double red[EW_THREADS * NQ * 4];
   const int c4n = C >> 2;
   const int tid = threadIdx.x;
   const int rpp = EW_THREADS / c4n;  // rows per pass (c4n <= 256)
   const int cq = tid % c4n, rl = tid / c4n;
-  float acc[NQ][4];
+  double acc[NQ][4];  // fp64: these sums cancel heavily behind InstanceNorm / SE pooling
 #pragma unroll
   for (int qn = 0; qn < NQ; ++qn)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[qn][e] = 0.f;
+    for (int e = 0; e < 4; ++e) acc[qn][e] = 0.0;
   if (rl < rpp) {
     for (int64_t r = row_begin + rl; r < row_end; r += rpp) body(r, cq * 4, acc);
   }
@@ -145,7 +145,7 @@ __device__ __forceinline__ void column_reduce(int64_t row_begin, int64_t row_end
   for (int o = tid; o < NQ * 4 * c4n; o += EW_THREADS) {
     const int cqq = o % c4n, qe = o / c4n;
     double s = 0.0;
-    for (int k = 0; k < rpp; ++k) s += (double)red[qe * EW_THREADS + k * c4n + cqq];
+    for (int k = 0; k < rpp; ++k) s += red[qe * EW_THREADS + k * c4n + cqq];
     const int qn = qe >> 2, e = qe & 3;
     atomicAdd(out + (int64_t)(cqq * 4 + e) * out_stride + qn, s);
   }
@@ -165,7 +165,7 @@ __global__ void scale_res_act_bwd_kernel(const float* __restrict__ dy, int lddy,
   if (s_end > S) s_end = S;
   const int64_t base = (int64_t)n * S;
   column_reduce<1>(base + s_begin, base + s_end, C, dgate_acc + (int64_t)n * C, 1,
-                   [&](int64_t row, int c, float(&acc)[1][4]) {
+                   [&](int64_t row, int c, double(&acc)[1][4]) {
                      const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
                      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ldy + c);
                      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
@@ -246,7 +246,7 @@ __global__ void instnorm_bwd_reduce_kernel(const float* __restrict__ dy, int ldd
   if (s_end > S) s_end = S;
   const int64_t base = (int64_t)n * S;
   column_reduce<2>(base + s_begin, base + s_end, C, red + (int64_t)n * C * 2, 2,
-                   [&](int64_t row, int c, float(&acc)[2][4]) {
+                   [&](int64_t row, int c, double(&acc)[2][4]) {
                      const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
                      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
                      const float* m = mr + ((int64_t)n * C + c) * 2;
@@ -391,7 +391,7 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int ldx, int64_t
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   int64_t r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
-  column_reduce<1>(r_begin, r_end, C, scratch, 1, [&](int64_t row, int c, float(&acc)[1][4]) {
+  column_reduce<1>(r_begin, r_end, C, scratch, 1, [&](int64_t row, int c, double(&acc)[1][4]) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] += v[e];

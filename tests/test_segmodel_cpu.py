@@ -37,14 +37,27 @@ def check(cfg, shape, device, tol):
     m, sd = build(cfg, device)
     x = det_input("seg.x", shape, "randn")
     out, out_up, skips = m(x.clone().to(device), return_inetermediate_feature=True)
-    loss = out.float().mean() + out_up.float().square().mean() + skips[1].abs().mean()
+    # random projections as the loss: a plain mean of InstanceNorm-ed features makes the gradients
+    # cancel to ~0 and turns any fp32 rounding into a huge relative error (also in torch's own fp32)
+    g1, g2, g3 = (det_input(n, tuple(t.shape), "randn") for n, t in (("g1", out), ("g2", out_up), ("g3", skips[1])))
+    loss = (out * g1.to(device)).mean() + (out_up * g2.to(device)).mean() + (skips[1] * g3.to(device)).mean()
     loss.backward()
-    osd = {k: v.clone().requires_grad_() for k, v in sd.items() if k in so.segmodel_shapes(cfg)}
-    r_out, r_up, r_skips = so.seg_model(osd, x.clone(), cfg, return_features=True)
-    (r_out.mean() + r_up.square().mean() + r_skips[1].abs().mean()).backward()
+    # Two oracles: fp64 is the reference value; fp32 (the reference's own CPU precision) calibrates how
+    # much of the deviation is plain fp32 rounding.  Deep InstanceNorm stacks amplify rounding in the
+    # backward pass: torch's fp32 gradients themselves sit ~4e-3 from fp64 on the 6-stage plans, so the
+    # gradient bar is "within 1e-3, or within 6x the fp32 oracle's own distance from fp64" (sums that
+    # cancel, e.g. a transposed-conv bias in front of an InstanceNorm, are the worst case: 4x observed).
+    runs = {}
+    for dt in (torch.float64, torch.float32):
+        osd = {k: v.to(dt).requires_grad_() for k, v in sd.items() if k in so.segmodel_shapes(cfg)}
+        r = so.seg_model(osd, x.to(dt), cfg, return_features=True)
+        ((r[0] * g1.to(dt)).mean() + (r[1] * g2.to(dt)).mean() + (r[2][1] * g3.to(dt)).mean()).backward()
+        runs[dt] = (osd, r)
+    osd, (r_out, r_up, r_skips) = runs[torch.float64]
+    osd32 = runs[torch.float32][0]
 
     def rel(a, b):
-        return float((a.detach().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
+        return float((a.detach().cpu().double() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
     assert out.shape == r_out.shape and out_up.shape == r_up.shape
     assert rel(out, r_out) < tol and rel(out_up, r_up) < tol
     for a, b in zip(skips, r_skips):
@@ -54,7 +67,9 @@ def check(cfg, shape, device, tol):
         if v.grad is None or "conv.bias" in k:   # d(conv bias) is identically 0 behind InstanceNorm
             continue
         n = float(v.grad.norm())
-        assert float((params[k].grad.cpu() - v.grad).norm()) <= 10 * tol * n + 1e-7, k
+        err = float((params[k].grad.cpu().double() - v.grad).norm())
+        err32 = float((osd32[k].grad.double() - v.grad).norm())
+        assert err <= max(10 * tol * n, 6 * err32) + 1e-7, (k, err / n, err32 / n)
 
 
 def test_segmodel_small_plan(emu):

@@ -14,7 +14,7 @@ def test_segmodel_small_plan_gpu():
 
 
 def test_segmodel_aniso_plan_gpu():
-    check(so.ANISO_PLAN, (1, 1, 8, 64, 64), "cuda:0", 1e-3 / 10)
+    check(so.ANISO_PLAN, (1, 1, 16, 96, 96), "cuda:0", 1e-3 / 10)
 
 
 def test_segmodel_cfg1_iso_plan_64cube_gpu():
@@ -26,11 +26,11 @@ def test_segmodel_cfg1_iso_plan_64cube_gpu():
     assert tuple(out.shape) == (1, 2, 64, 64, 64) and tuple(out_up.shape) == (1, 2, 256, 64, 64)
     (out.float().mean() + out_up.float().mean()).backward()
     assert torch.isfinite(out).all() and torch.isfinite(out_up).all()
-    osd = {k: v for k, v in sd.items() if k in so.segmodel_shapes(so.ISO_PLAN)}
+    osd = {k: v.double() for k, v in sd.items() if k in so.segmodel_shapes(so.ISO_PLAN)}
     with torch.no_grad():
-        r_out, r_up = so.seg_model(osd, x.clone(), so.ISO_PLAN)
+        r_out, r_up = so.seg_model(osd, x.double(), so.ISO_PLAN)
     for a, b in ((out, r_out), (out_up, r_up)):
-        assert float((a.detach().cpu() - b).abs().max() / b.abs().max()) < 1e-3
+        assert float((a.detach().cpu().double() - b).abs().max() / b.abs().max()) < 1e-3
     # label maps: exact where the logit margin is clear of the numerical noise, mismatches reported otherwise
     for a, b in ((out, r_out), (out_up, r_up)):
         la, lb = a.detach().cpu().argmax(1), b.argmax(1)
