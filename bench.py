@@ -30,6 +30,19 @@ def build_model(n_inputs, dev):
     return UNet_3D_3D(img_channels=1, block="unet_18", n_inputs=n_inputs, n_outputs=4).to(dev)
 
 
+def build_seg_model(dev):
+    """BASELINE.json configs[2]: nnU-Net 3d_fullres SegModel, isotropic plan, upscale 4."""
+    import torch.nn as nn
+    from rehrseg_amd.models.seg_model import SegModel
+    torch.manual_seed(0)
+    return SegModel(input_channels=1, num_classes=2, n_stages=6, upscale=4,
+                    features_per_stage=[32, 64, 128, 256, 320, 320], conv_op=nn.Conv3d,
+                    kernel_sizes=[[3, 3, 3]] * 6, strides=[[1, 1, 1]] + [[2, 2, 2]] * 5, n_conv_per_stage=[2] * 6,
+                    n_conv_per_stage_decoder=[2] * 5, conv_bias=True, norm_op=nn.InstanceNorm3d,
+                    norm_op_kwargs={"eps": 1e-5, "affine": True}, dropout_op=None, dropout_op_kwargs=None,
+                    nonlin=nn.LeakyReLU, nonlin_kwargs={"inplace": True}, deep_supervision=False).to(dev)
+
+
 def cpu_baseline(size):
     """The oracle (a CPU port of the reference's path) on the host cores, one step."""
     from oracle import flavr_oracle as fo
@@ -57,6 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=128, help="patch edge (128 = BASELINE config)")
+    ap.add_argument("--workload", choices=["flavr", "seg"], default="flavr",
+                    help="flavr = configs[1] (headline); seg = configs[2] (SegModel 2x1x128^3, secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -76,21 +91,45 @@ def main():
     from rehrseg_amd.parallel import PatchParallel
 
     size = args.size
-    model = build_model(size, dev)
-    pp = PatchParallel(model)
-    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # every rank draws its own patch
-    x = torch.rand(1, 1, size, size, size, generator=g).to(dev)
-    tgt = torch.rand(1, 1, 4, size, size, generator=g).to(dev)
+    if args.workload == "flavr":
+        model = build_model(size, dev)
+        pp = PatchParallel(model)
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
+        x = torch.rand(1, 1, size, size, size, generator=g).to(dev)
+        tgt = torch.rand(1, 1, 4, size, size, generator=g).to(dev)
+        patches_per_step = 1
+        workload = (f"FLAVR UNet_3D_3D(1,'unet_18',{size},4) fwd+bwd+Adam, 1x1x{size}^3 patch per GPU, "
+                    "random-init weights")
 
-    def step():
-        pp.zero_grad()
-        out = model(x.clone())  # forward subtracts the mean in place, like the reference
-        loss = (out - tgt).abs().mean()
-        loss.backward()
-        pp.reduce_gradients()
-        opt.step()
-        return loss
+        def step():
+            pp.zero_grad()
+            out = model(x.clone())  # forward subtracts the mean in place, like the reference
+            loss = (out - tgt).abs().mean()
+            loss.backward()
+            pp.reduce_gradients()
+            opt.step()
+            return loss
+    else:
+        model = build_seg_model(dev)
+        pp = PatchParallel(model)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.99, nesterov=True, weight_decay=3e-5)
+        x = torch.randn(2, 1, size, size, size, generator=g).to(dev)
+        lab_lr = torch.randint(0, 2, (2, size, size, size), generator=g).to(dev)
+        lab_hr = torch.randint(0, 2, (2, 4 * size, size, size), generator=g).to(dev)
+        patches_per_step = 2
+        workload = (f"SegModel (nnU-Net 3d_fullres isotropic plan, upscale 4) fwd+bwd+SGD, 2x1x{size}^3 per GPU, "
+                    "CE on LR and HR logits, random-init weights")
+        ce = torch.nn.functional.cross_entropy
+
+        def step():
+            pp.zero_grad()
+            out, out_up = model(x)
+            loss = ce(out, lab_lr) + ce(out_up, lab_hr)
+            loss.backward()
+            pp.reduce_gradients()
+            opt.step()
+            return loss
 
     for _ in range(args.warmup):
         step()
@@ -115,11 +154,11 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         rec = {
-            "metric": "3D patches/sec (fwd+bwd, 128^3 fp32)", "value": world * args.steps / elapsed,
+            "metric": "3D patches/sec (fwd+bwd, 128^3 fp32)", "value": world * patches_per_step * args.steps / elapsed,
             "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"FLAVR UNet_3D_3D(1,'unet_18',{size},4) fwd+bwd+Adam, 1x1x{size}^3 patch per GPU, "
-                                   "random-init weights", "patches_per_gpu": 1, "global_batch": world,
+            "config": {"workload": workload, "patches_per_gpu": patches_per_step,
+                       "global_batch": world * patches_per_step,
                        "parallelism": f"dp{world} (patch-parallel, flat-bucket RCCL all-reduce)"},
             "loss": float(loss.item()),
         }
@@ -141,7 +180,7 @@ def main():
                                          "algorithmic_gflop_per_step": wg["flops"] / args.steps / 1e9}
             tot = sum(v["seconds"] for v in prof.values())
             rec["mfma_kernel_ms_per_step"] = tot / args.steps * 1e3
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "flavr":
             rec["cpu_baseline"] = cpu_baseline(size)
         print(json.dumps(rec), flush=True)
     if world > 1:

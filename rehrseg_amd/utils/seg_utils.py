@@ -1,0 +1,161 @@
+"""Losses and normalisation used by the two training loops, under the reference's import
+path (`utils.seg_utils`): same names, arguments and numerics as utils/seg_utils.py:137-156
+(zscore_normalization), :289-372 (RobustCrossEntropyLoss, DC_and_weighted_CE_loss,
+_build_loss) and :786-885 (DiceLoss, BCEDiceLoss).
+
+These are HBM-bound reductions over the logits; they run as torch ops on the device for now
+(SURVEY section 8f-1 ranks fusing them into one pass as the next row after the conv path).
+`MemoryEfficientSoftDiceLoss` lives in nnunetv2==2.3.1 (absent offline): its published
+formula is restated in `SoftDiceLoss` below -- that term's parity is unpinned.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def zscore_normalization(image):
+    """Per-sample z-score of channel 0, IN PLACE on the caller's tensor (ref :137-149);
+    returns the normalised channel as (B, 1, ...)."""
+    if not isinstance(image, torch.Tensor):
+        image = image.astype(np.float32, copy=False)
+        image -= image.mean()
+        image /= max(image.std(), 1e-8)
+        return image
+    outs = []
+    for i in range(image.shape[0]):
+        view = image[i:i + 1, 0, ...]
+        mean, std = view.mean(), view.std()
+        view -= mean
+        view /= max(std, 1e-8)
+        outs.append(view)
+    return torch.stack(outs, dim=0)
+
+
+class RobustCrossEntropyLoss(nn.CrossEntropyLoss):
+    """CE on float targets with an optional uncertainty weight (ref :289-304).  The weight has a
+    channel axis the loss map lacks, so (B,D,H,W) * (B,1,D,H,W) broadcasts to (B,B,D,H,W)
+    before the mean -- reproduced as is."""
+
+    def forward(self, input, target, uncertainty=None):
+        if target.ndim == input.ndim:
+            assert target.shape[1] == 1
+            target = target[:, 0]
+        loss = super().forward(input, target.long())
+        if uncertainty is not None:
+            loss = loss * uncertainty
+        return loss.mean()
+
+
+class SoftDiceLoss(nn.Module):
+    """nnunetv2 MemoryEfficientSoftDiceLoss, restated (unpinned): -mean over (b, c) of
+    (2*intersect + smooth) / clip(sum_gt + sum_pred + smooth, 1e-8)."""
+
+    def __init__(self, apply_nonlin=None, batch_dice=False, do_bg=True, smooth=1.0, ddp=False):
+        super().__init__()
+        if ddp and batch_dice:
+            raise NotImplementedError("REHRSeg passes batch_dice=False, ddp=False (utils/seg_utils.py:356-357)")
+        self.apply_nonlin, self.batch_dice, self.do_bg, self.smooth = apply_nonlin, batch_dice, do_bg, smooth
+
+    def forward(self, x, y, loss_mask=None):
+        if self.apply_nonlin is not None:
+            x = self.apply_nonlin(x)
+        axes = tuple(range(2, x.ndim))
+        with torch.no_grad():
+            if x.ndim != y.ndim:
+                y = y.view((y.shape[0], 1, *y.shape[1:]))
+            if x.shape == y.shape:
+                y_onehot = y
+            else:
+                y_onehot = torch.zeros(x.shape, device=x.device, dtype=torch.bool)
+                y_onehot.scatter_(1, y.long(), 1)
+            if not self.do_bg:
+                y_onehot = y_onehot[:, 1:]
+            sum_gt = y_onehot.sum(axes) if loss_mask is None else (y_onehot * loss_mask).sum(axes)
+        if not self.do_bg:
+            x = x[:, 1:]
+        if loss_mask is None:
+            intersect, sum_pred = (x * y_onehot).sum(axes), x.sum(axes)
+        else:
+            intersect, sum_pred = (x * y_onehot * loss_mask).sum(axes), (x * loss_mask).sum(axes)
+        if self.batch_dice:
+            intersect, sum_pred, sum_gt = intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)
+        dc = (2 * intersect + self.smooth) / torch.clip(sum_gt + sum_pred + self.smooth, 1e-8)
+        return -dc.mean()
+
+
+def softmax_helper_dim1(x):
+    return torch.softmax(x, 1)
+
+
+class DC_and_weighted_CE_loss(nn.Module):
+    """ref :306-351: weight_ce * CE(uncertainty-weighted) + weight_dice * soft Dice."""
+
+    def __init__(self, soft_dice_kwargs, ce_kwargs, weight_ce=1, weight_dice=1, ignore_label=None,
+                 dice_class=SoftDiceLoss):
+        super().__init__()
+        if ignore_label is not None:
+            ce_kwargs["ignore_index"] = ignore_label
+        self.weight_dice, self.weight_ce, self.ignore_label = weight_dice, weight_ce, ignore_label
+        self.ce = RobustCrossEntropyLoss(**ce_kwargs)
+        self.dc = dice_class(apply_nonlin=softmax_helper_dim1, **soft_dice_kwargs)
+
+    def forward(self, net_output, target, uncertainty=None):
+        if self.ignore_label is not None:
+            assert target.shape[1] == 1
+            mask = target != self.ignore_label
+            target_dice = torch.where(mask, target, 0)
+            num_fg = mask.sum()
+        else:
+            target_dice, mask = target, None
+        dc_loss = self.dc(net_output, target_dice, loss_mask=mask) if self.weight_dice != 0 else 0
+        ce_loss = self.ce(net_output, target[:, 0], uncertainty) \
+            if self.weight_ce != 0 and (self.ignore_label is None or num_fg > 0) else 0
+        return self.weight_ce * ce_loss + self.weight_dice * dc_loss
+
+
+def _build_loss(enable_deep_supervision=False, weight_dice=1):
+    """ref :353-372 without the DeepSupervisionWrapper branch (the reference trains with
+    enable_deep_supervision=False, train_all.py:471)."""
+    if enable_deep_supervision:
+        raise NotImplementedError("deep supervision wrapper (nnunetv2) is not part of the hot path")
+    return DC_and_weighted_CE_loss({"batch_dice": False, "smooth": 1e-5, "do_bg": False, "ddp": False},
+                                   {"reduction": "none"}, weight_ce=1, weight_dice=weight_dice, ignore_label=None,
+                                   dice_class=SoftDiceLoss)
+
+
+def compute_per_channel_dice(input, target, epsilon=1e-6, weight=None):
+    """ref :829-857: 2*sum(p*t) / clamp(sum(p^2) + sum(t^2), eps) per channel."""
+    assert input.size() == target.size()
+    c = input.size(1)
+    p = input.transpose(0, 1).reshape(c, -1)
+    t = target.transpose(0, 1).reshape(c, -1).float()
+    inter = (p * t).sum(-1)
+    if weight is not None:
+        inter = weight * inter
+    return 2 * (inter / ((p * p).sum(-1) + (t * t).sum(-1)).clamp(min=epsilon))
+
+
+class DiceLoss(nn.Module):
+    def __init__(self, weight=None, normalization="sigmoid"):
+        super().__init__()
+        self.register_buffer("weight", weight)
+        assert normalization in ("sigmoid", "softmax", "none")
+        self.normalization = {"sigmoid": torch.sigmoid, "softmax": lambda x: torch.softmax(x, 1),
+                              "none": lambda x: x}[normalization]
+
+    def forward(self, input, target):
+        return 1.0 - torch.mean(compute_per_channel_dice(self.normalization(input), target, weight=self.weight))
+
+
+class BCEDiceLoss(nn.Module):
+    """alpha * BCEWithLogits + beta * Dice (ref :872-885)."""
+
+    def __init__(self, alpha, beta):
+        super().__init__()
+        self.alpha, self.beta = alpha, beta
+        self.bce = nn.BCEWithLogitsLoss()
+        self.dice = DiceLoss()
+
+    def forward(self, input, target):
+        return self.alpha * self.bce(input, target) + self.beta * self.dice(input, target)

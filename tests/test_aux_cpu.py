@@ -1,0 +1,108 @@
+"""Distiller, losses, zscore and the teacher pass: oracle and product against the fixture that
+tools/gen_golden_losses.py captured from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aux_oracle as ao
+from oracle import flavr_oracle as fo
+from oracle.detinit import det_input, det_state_dict, det_tensor
+from rehrseg_amd.models.seg_model import Distiller
+from rehrseg_amd.train_steps import get_intermediate_features
+from rehrseg_amd.utils import seg_utils as su
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "aux_losses_teacher.npz"))
+close = lambda a, b, tol=1e-5: np.allclose(np.asarray(a), np.asarray(b), rtol=tol, atol=tol * 1e-1)
+
+
+def _dist_inputs():
+    return det_input("dist.s", (2, 64, 6, 16, 16)).requires_grad_(), det_input("dist.t", (2, 64, 6, 16, 16))
+
+
+def test_distiller_oracle_and_product():
+    w, b = det_tensor("distill.weight", (64, 64, 1, 1, 1)).requires_grad_(), det_tensor("distill.bias", (64,)).requires_grad_()
+    fs, ft = _dist_inputs()
+    loss = ao.distiller_loss(w, b, fs, ft, 0.0, 1.0, 1.0)
+    loss.backward()
+    assert abs(loss.item() - float(G["dist_loss"])) < 1e-6
+    assert close(fs.grad.numpy(), G["dist_grad_fs"], 1e-4) and close(w.grad.numpy(), G["dist_grad_w"], 1e-4)
+    assert abs(ao.distiller_loss(w, b, fs.detach(), ft, 0.5, 0.0, 0.0).item() - float(G["dist_l1_loss"])) < 1e-6
+    m = Distiller(64, 64, 0.0, 1.0, 1.0)
+    m.load_state_dict({k: det_tensor(k, tuple(v.shape)) for k, v in m.state_dict().items()})
+    fs2, _ = _dist_inputs()
+    l2 = m(fs2, ft)
+    l2.backward()
+    assert abs(l2.item() - float(G["dist_loss"])) < 1e-6
+    assert close(fs2.grad.numpy(), G["dist_grad_fs"], 1e-4) and close(m.distill.bias.grad.numpy(), G["dist_grad_b"], 1e-4)
+
+
+def test_losses_oracle_and_product():
+    x = det_input("bcedice.x", (2, 1, 4, 16, 16)).requires_grad_()
+    t = det_input("bcedice.t", (2, 1, 4, 16, 16), "randint2")
+    for fn in (ao.bce_dice, su.BCEDiceLoss(1.0, 1.0)):
+        x.grad = None
+        l = fn(x, t)
+        l.backward()
+        assert abs(l.item() - float(G["bcedice_loss"])) < 1e-6 and close(x.grad.numpy(), G["bcedice_grad"], 1e-4)
+    lg = det_input("ce.x", (2, 2, 4, 8, 8)).requires_grad_()
+    tg = det_input("ce.t", (2, 1, 4, 8, 8), "randint2")
+    un = det_input("ce.u", (2, 1, 4, 8, 8), "rand")
+    for fn in (ao.robust_ce, su.RobustCrossEntropyLoss(reduction="none")):
+        lg.grad = None
+        l = fn(lg, tg[:, 0], un)
+        l.backward()
+        assert abs(l.item() - float(G["ce_unc_loss"])) < 1e-6 and close(lg.grad.numpy(), G["ce_unc_grad"], 1e-4)
+        assert abs(fn(lg.detach(), tg[:, 0], None).item() - float(G["ce_plain_loss"])) < 1e-6
+
+
+def test_zscore_in_place():
+    for fn in (ao.zscore, su.zscore_normalization):
+        z = torch.from_numpy(G["zscore_in"]).clone()
+        out = fn(z)
+        assert close(out.numpy(), G["zscore_out"]) and close(z.numpy(), G["zscore_in_after"])
+
+
+def test_dc_and_ce_loss_runs_and_matches_manual_formula():
+    loss = su._build_loss(False, weight_dice=1)
+    lg = det_input("ce.x", (2, 2, 4, 8, 8)).requires_grad_()
+    tg = det_input("ce.t", (2, 1, 4, 8, 8), "randint2")
+    l = loss(lg, tg, None)
+    p = torch.softmax(lg, 1)[:, 1:]
+    oh = (tg == 1).float()
+    dc = (2 * (p * oh).sum((2, 3, 4)) + 1e-5) / torch.clip(oh.sum((2, 3, 4)) + p.sum((2, 3, 4)) + 1e-5, 1e-8)
+    ref = torch.nn.functional.cross_entropy(lg, tg[:, 0].long()) - dc.mean()
+    assert abs(l.item() - ref.item()) < 1e-6
+    l.backward()
+    assert torch.isfinite(lg.grad).all()
+
+
+def test_teacher_pass_oracle():
+    sd = det_state_dict(fo.flavr_shapes(2, 4, 4, True))
+    img = det_input("gif.img", (2, 1, 6, 32, 32), "rand")
+    lab = det_input("gif.lab", (2, 1, 6, 32, 32), "randint2")
+    with torch.no_grad():
+        f = ao.teacher_features(sd, img, lab)
+    assert close(img.numpy(), G["gif_img_after"])
+    for i in range(5):
+        assert list(f[i].shape) == list(G[f"gif_shape{i}"])
+        assert close(f[i].double().mean((3, 4)).numpy(), G[f"gif_mean{i}"], 1e-4)
+    assert close(f[1].numpy(), G["gif_feat1"], 1e-4)
+
+
+@pytest.mark.parametrize("levels", [None, (1,)])
+def test_teacher_pass_product_batched(emu, levels):
+    from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+    m = UNet_3D_3D(2, "unet_18", 4, 4, use_uncertainty=True).eval()
+    m.load_state_dict({k: det_tensor(k, tuple(v.shape)) for k, v in m.state_dict().items()})
+    img = det_input("gif.img", (2, 1, 6, 32, 32), "rand")
+    lab = det_input("gif.lab", (2, 1, 6, 32, 32), "randint2")
+    with torch.no_grad():
+        f = get_intermediate_features(m, img, lab, torch.device("cpu"), levels=levels)
+    assert close(img.numpy(), G["gif_img_after"])
+    assert sorted(f) == ([0, 1, 2, 3, 4] if levels is None else [1])
+    for i in f:
+        assert list(f[i].shape) == list(G[f"gif_shape{i}"])
+        assert close(f[i].double().mean((3, 4)).numpy(), G[f"gif_mean{i}"], 1e-3)
+    assert close(f[1].numpy(), G["gif_feat1"], 1e-3)

@@ -1,0 +1,85 @@
+"""The two training steps end to end on the MI355X modules (losses, teacher pass, distillation,
+optimizer) against the same step composed from the CPU oracles."""
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import aux_oracle as ao
+from oracle import flavr_oracle as fo
+from oracle import segmodel_oracle as so
+from oracle.detinit import det_input, det_tensor
+from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+from rehrseg_amd.models.seg_model import Distiller
+from rehrseg_amd.train_steps import train_segsr_step, train_sr_step
+from rehrseg_amd.utils import seg_utils as su
+from test_segmodel_cpu import build, canonical
+
+pytestmark = pytest.mark.gpu
+PLAN = dict(n_stages=3, features_per_stage=[32, 64, 96], kernel_sizes=[[1, 3, 3], [1, 3, 3], [3, 3, 3]],
+            strides=[[1, 1, 1], [1, 2, 2], [2, 2, 2]], n_conv_per_stage=[2, 2, 2], n_conv_per_stage_decoder=[2, 2],
+            num_classes=2, upscale=4)
+
+
+def _flavr(unc, dev):
+    m = UNet_3D_3D(2, "unet_18", 4, 4, use_uncertainty=unc)
+    sd = {k: det_tensor(k, tuple(v.shape)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    return m.to(dev), sd
+
+
+def test_train_sr_step_uncertainty():
+    dev = torch.device("cuda:0")
+    m, sd = _flavr(True, dev)
+    lr_p = det_input("sr.lr", (2, 2, 4, 32, 32), "rand")
+    hr_p = det_input("sr.hr", (2, 2, 16, 32, 32), "rand")
+    hr_p[:, 1:] = (hr_p[:, 1:] > 0.5).float()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    w_before = m.outconv[1].weight.detach().clone()
+    loss = train_sr_step(m, opt, None, lr_p.clone().to(dev), hr_p.to(dev), nn.L1Loss(), su.BCEDiceLoss(1.0, 1.0), 4.0, 4,
+                         True)
+    # oracle composition of train_all.py:122-134
+    osd = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    hat, unc = fo.unet_3d_3d(osd, lr_p.clone(), 2, 4, 4, True)
+    hr = hr_p[:, :, 4:8]
+    ref = (hat[:, 0:1] - hr[:, 0:1]).abs().mean()
+    ref = ref + torch.mean((hat[:, 0:1] - hr[:, 0:1]).abs() / unc + torch.log(unc))
+    ref = ref + (unc - (hat[:, 0:1].detach() - hr[:, 0:1]).abs()).abs().mean()
+    ref = ref + ao.bce_dice(hat[:, 1:], hr[:, 1:])
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    assert torch.equal(m.outconv[1].weight.detach().cpu(), w_before.cpu())  # unused by the UASR head: no update
+    assert not torch.equal(m.feature_fuse1.conv[0].weight.detach().cpu(), sd["feature_fuse1.conv.0.weight"])
+
+
+def test_train_segsr_step_with_distillation():
+    dev = torch.device("cuda:0")
+    teacher, tsd = _flavr(True, dev)
+    teacher.eval()
+    student, ssd = build(PLAN, dev)
+    dist = Distiller(64, 64, 0.0, 1.0, 1.0)
+    dsd = {k: det_tensor(k, tuple(v.shape)) for k, v in dist.state_dict().items()}
+    dist.load_state_dict(dsd)
+    dist = dist.to(dev)
+    img = det_input("st2.img", (2, 1, 6, 32, 32), "rand") * 2 + 0.5
+    lab_lr = det_input("st2.lr", (2, 1, 6, 32, 32), "randint2")
+    lab_hr = det_input("st2.hr", (2, 1, 24, 32, 32), "randint2")
+    unc = 1 - det_input("st2.u", (2, 1, 6, 32, 32), "rand") * 0.99
+    import itertools
+    opt = torch.optim.SGD(itertools.chain(student.parameters(), dist.parameters()), lr=1e-3, momentum=0.99,
+                          nesterov=True, weight_decay=3e-5)
+    img_dev = img.clone().to(dev)
+    loss = train_segsr_step(student, teacher, dist, opt, img_dev, lab_lr.to(dev), lab_hr.to(dev), unc.to(dev),
+                            su._build_loss(False, weight_dice=0), su._build_loss(False, weight_dice=1))
+    # oracle composition of train_all.py:531-552
+    img_o = img.clone()
+    with torch.no_grad():
+        tf = ao.teacher_features(tsd, img_o, lab_lr)
+    assert torch.allclose(img_dev.cpu(), img_o, atol=1e-5)  # z-scored in place, then fed to the student
+    osd = {k: v.clone().requires_grad_() for k, v in ssd.items() if k in so.segmodel_shapes(PLAN)}
+    seg_lr, seg_sr, skips = so.seg_model(osd, img_o, PLAN, return_features=True)
+    ref = ao.robust_ce(seg_lr, lab_lr[:, 0], unc)
+    p = torch.softmax(seg_sr, 1)[:, 1:]
+    oh = (lab_hr == 1).float()
+    dc = (2 * (p * oh).sum((2, 3, 4)) + 1e-5) / torch.clip(oh.sum((2, 3, 4)) + p.sum((2, 3, 4)) + 1e-5, 1e-8)
+    ref = ref + ao.robust_ce(seg_sr, lab_hr[:, 0], None) - dc.mean()
+    ref = ref + ao.distiller_loss(dsd["distill.weight"], dsd["distill.bias"], skips[1], tf[1], 0.0, 1.0, 1.0)
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
