@@ -37,8 +37,13 @@ struct GGParams {
   int64_t wp_bytes;
 };
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams p) {
+// LDSBUF = 2: double-buffered LDS tiles, one barrier per K step (register-heavy 128x128 tile,
+//             2 blocks per CU anyway).
+// LDSBUF = 1: one LDS tile + the two register sets as the pipeline, two barriers per K step;
+//             halves LDS so the narrow-N tiles run 3 blocks per CU, whose MFMA phases fill each
+//             other's barrier bubbles.
+template <int BM, int BN, int WGM, int WGN, int LDSBUF>
+__global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_kernel(const GGParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int FM = WTM / 32, FN = WTN / 32;
   constexpr int AROWS = BM / 32, BROWS = BN / 32;  // rows per thread per tile
@@ -46,9 +51,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
   const rehr_gather_gemm_desc& d = p.d;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                               // [2][BM][LDS_LD]
-  float* Bs = smem + 2 * BM * LDS_LD;             // [2][BN][LDS_LD]
-  int* row_out = (int*)(Bs + 2 * BN * LDS_LD);    // [BM] destination voxel or -1
+  float* As = smem;                                    // [LDSBUF][BM][LDS_LD]
+  float* Bs = smem + LDSBUF * BM * LDS_LD;             // [LDSBUF][BN][LDS_LD]
+  int* row_out = (int*)(Bs + LDSBUF * BN * LDS_LD);    // [BM] destination voxel or -1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -270,16 +275,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
   // Invariant at the top: tile s is staged in LDS[0], tile s+1 is in flight in set 1.
   // Fetches run past the last tile (the iterator is then beyond Cin: such loads are
   // out of range or harmless and never consumed), which keeps each half branch-free.
-  for (int s = 0; s < nsteps; s += 2) {
-    issue_loads(ra0, rb0);            // tile s+2
-    compute(0);
-    commit_loads(1, ra1, rb1);        // tile s+1
-    __syncthreads();
-    if (s + 1 >= nsteps) break;
-    issue_loads(ra1, rb1);            // tile s+3
-    compute(1);
-    commit_loads(0, ra0, rb0);        // tile s+2
-    __syncthreads();
+  if (LDSBUF == 2) {
+    for (int s = 0; s < nsteps; s += 2) {
+      issue_loads(ra0, rb0);            // tile s+2
+      compute(0);
+      commit_loads(1, ra1, rb1);        // tile s+1
+      __syncthreads();
+      if (s + 1 >= nsteps) break;
+      issue_loads(ra1, rb1);            // tile s+3
+      compute(1);
+      commit_loads(0, ra0, rb0);        // tile s+2
+      __syncthreads();
+    }
+  } else {
+    for (int s = 0; s < nsteps; s += 2) {
+      issue_loads(ra0, rb0);            // tile s+2
+      compute(0);
+      __syncthreads();                  // every wave is done reading tile s
+      commit_loads(0, ra1, rb1);        // tile s+1
+      __syncthreads();
+      if (s + 1 >= nsteps) break;
+      issue_loads(ra1, rb1);            // tile s+3
+      compute(0);
+      __syncthreads();
+      commit_loads(0, ra0, rb0);        // tile s+2
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: bias + activation + store (+ statistics) ----
@@ -316,11 +337,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_kernel(const GGParams
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int LDSBUF>
 int launch_gg(const GGParams& p, hipStream_t stream) {
-  const size_t smem = (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(float) + BM * sizeof(int);
+  const size_t smem = (size_t)LDSBUF * (BM + BN) * LDS_LD * sizeof(float) + BM * sizeof(int);
   static bool attr_set = false;
-  auto kern = gather_gemm_kernel<BM, BN, WGM, WGN>;
+  auto kern = gather_gemm_kernel<BM, BN, WGM, WGN, LDSBUF>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -392,12 +413,12 @@ extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* strea
   hipStream_t st = (hipStream_t)stream;
   if (d.Npad % 128 == 0) {
     p.n_tiles = d.Npad / 128;
-    return launch_gg<128, 128, 2, 2>(p, st);
+    return launch_gg<128, 128, 2, 2, 2>(p, st);
   } else if (d.Npad % 64 == 0) {
     p.n_tiles = d.Npad / 64;
-    return launch_gg<128, 64, 2, 2>(p, st);
+    return launch_gg<128, 64, 2, 2, 1>(p, st);
   } else {
     p.n_tiles = d.Npad / 32;
-    return launch_gg<128, 32, 4, 1>(p, st);
+    return launch_gg<128, 32, 4, 1, 1>(p, st);
   }
 }
