@@ -566,6 +566,257 @@ __global__ __launch_bounds__(256) void small_cout_wgrad_kernel(const rehr_direct
   }
 }
 
+
+// ---- coalesced variants for Cin in {16, 32, 64}: CG = Cin/4 adjacent lanes share one voxel,
+// each owning a 4-channel quad, so a wave-load is whole 64..256-byte voxel records instead
+// of 64 scattered 16-byte pieces.  Partial sums are combined across the CG lanes at the end.
+template <int CO, int CG>
+__global__ __launch_bounds__(256) void small_cout_fwd_cg_kernel(const rehr_direct_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [T][CO][Cin]
+  const int T = d.KD * d.KH * d.KW;
+  for (int i = threadIdx.x; i < CO * d.Cin * T; i += 256) {
+    const int co = i / (d.Cin * T), rem = i - co * d.Cin * T;
+    const int ci = rem / T, t = rem - ci * T;
+    wl[(t * CO + co) * d.Cin + ci] = (co < d.Cout) ? d.w[((int64_t)co * d.Cin + ci) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int c4 = (threadIdx.x % CG) * 4;
+  const int wg = (d.Wo + SC_VOX - 1) / SC_VOX;
+  const int64_t groups = (int64_t)d.N * d.Do * d.Ho * wg;
+  constexpr int GPB = 256 / CG;  // voxel groups per block
+  for (int64_t g0 = (int64_t)blockIdx.x * GPB; g0 < groups; g0 += (int64_t)gridDim.x * GPB) {
+    const int64_t gidx = g0 + threadIdx.x / CG;
+    const bool live = gidx < groups;
+    const int64_t gi = live ? gidx : 0;
+    const int gw = (int)(gi % wg);
+    int64_t r = gi / wg;
+    const int oh = (int)(r % d.Ho); r /= d.Ho;
+    const int od = (int)(r % d.Do);
+    const int n = (int)(r / d.Do);
+    const int ow0 = gw * SC_VOX;
+    float acc[SC_VOX][CO];
+#pragma unroll
+    for (int v = 0; v < SC_VOX; ++v)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[v][c] = 0.f;
+    const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx + c4;
+    for (int kd = 0; kd < d.KD; ++kd) {
+      const int id = od - d.pd + kd;
+      for (int kh = 0; kh < d.KH; ++kh) {
+        const int ih = oh - d.ph + kh;
+        const bool rowok = live && (unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi;
+        const float* xr = xn + ((int64_t)id * d.Hi + ih) * d.Wi * d.ldx;
+        const float* wr = wl + (kd * d.KH + kh) * d.KW * CO * d.Cin + c4;
+        f32x4 seg[SC_VOX + SC_MAXKW - 1];
+#pragma unroll
+        for (int j = 0; j < SC_VOX + SC_MAXKW - 1; ++j) {
+          const int iw = ow0 - d.pw + j;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (rowok && j < SC_VOX + d.KW - 1 && (unsigned)iw < (unsigned)d.Wi)
+            v = *reinterpret_cast<const f32x4*>(xr + (int64_t)iw * d.ldx);
+          seg[j] = v;
+        }
+#pragma unroll
+        for (int kw = 0; kw < SC_MAXKW; ++kw) {
+          if (kw < d.KW) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (kw * CO + c) * d.Cin);
+#pragma unroll
+              for (int v = 0; v < SC_VOX; ++v) {
+                const f32x4 xv = seg[v + kw];
+                acc[v][c] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+              }
+            }
+          }
+        }
+      }
+    }
+    // combine the CG channel quads of a voxel group (adjacent lanes)
+#pragma unroll
+    for (int v = 0; v < SC_VOX; ++v)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        float a = acc[v][c];
+#pragma unroll
+        for (int o = CG / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        acc[v][c] = a;
+      }
+    if (live && (threadIdx.x % CG) == 0) {
+      float* yo = d.y + ((((int64_t)n * d.Do + od) * d.Ho + oh) * d.Wo + ow0) * d.ldy;
+#pragma unroll
+      for (int v = 0; v < SC_VOX; ++v)
+        if (ow0 + v < d.Wo)
+#pragma unroll
+          for (int c = 0; c < CO; ++c)
+            if (c < d.Cout)
+              yo[(int64_t)v * d.ldy + c] = apply_act(acc[v][c] + (d.bias ? d.bias[c] : 0.f), d.act, d.slope);
+    }
+  }
+}
+
+// weight gradient, same lane mapping: a block owns (kd, kh) and a strip of output rows;
+// lane = (w position, channel quad); sums go through LDS atomics once per block.
+template <int CO, int CG>
+__global__ __launch_bounds__(256) void small_cout_wgrad_cg_kernel(const rehr_direct_conv_desc d,
+                                                                  float* __restrict__ slab, int rows_per_block) {
+  __shared__ float red[SC_MAXKW * 64 * 4];  // [kw][ci (<=64)][co (<=4)]
+  for (int i = threadIdx.x; i < SC_MAXKW * 64 * 4; i += 256) red[i] = 0.f;
+  __syncthreads();
+  int b = blockIdx.x;
+  const int kh = b % d.KH; b /= d.KH;
+  const int kd = b % d.KD; b /= d.KD;
+  const int strip = b;
+  const int cq = threadIdx.x % CG, wl_ = threadIdx.x / CG;
+  constexpr int WPB = 256 / CG;  // w positions per pass
+  const int64_t nrows = (int64_t)d.N * d.Do * d.Ho;
+  const int64_t row0 = (int64_t)strip * rows_per_block;
+  float acc[SC_MAXKW][4][CO];
+#pragma unroll
+  for (int kw = 0; kw < SC_MAXKW; ++kw)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[kw][e][c] = 0.f;
+  for (int rr = 0; rr < rows_per_block; ++rr) {
+    const int64_t row = row0 + rr;
+    if (row >= nrows) break;
+    const int oh = (int)(row % d.Ho);
+    const int64_t r2 = row / d.Ho;
+    const int od = (int)(r2 % d.Do);
+    const int n = (int)(r2 / d.Do);
+    const int id = od - d.pd + kd, ih = oh - d.ph + kh;
+    if ((unsigned)id >= (unsigned)d.Di || (unsigned)ih >= (unsigned)d.Hi) continue;
+    const float* yr = d.y + (((int64_t)n * d.Do + od) * d.Ho + oh) * d.Wo * d.ldy;
+    const float* xr = d.x + (((int64_t)n * d.Di + id) * d.Hi + ih) * d.Wi * d.ldx + cq * 4;
+    for (int ow = wl_; ow < d.Wo; ow += WPB) {
+      float dyv[CO];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) dyv[c] = (c < d.Cout) ? yr[(int64_t)ow * d.ldy + c] : 0.f;
+#pragma unroll
+      for (int kw = 0; kw < SC_MAXKW; ++kw) {
+        const int iw = ow - d.pw + kw;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (kw < d.KW && (unsigned)iw < (unsigned)d.Wi) xv = *reinterpret_cast<const f32x4*>(xr + (int64_t)iw * d.ldx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[kw][e][c] += xv[e] * dyv[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int kw = 0; kw < SC_MAXKW; ++kw)
+    if (kw < d.KW)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+          if (c < d.Cout) atomicAdd(&red[(kw * 64 + cq * 4 + e) * 4 + c], acc[kw][e][c]);
+  __syncthreads();
+  const int T = d.KD * d.KH * d.KW;
+  float* sb = slab + (int64_t)strip * d.Cout * d.Cin * T;
+  for (int i = threadIdx.x; i < d.KW * d.Cin * d.Cout; i += 256) {
+    const int c = i % d.Cout, ci = (i / d.Cout) % d.Cin, kw = i / (d.Cout * d.Cin);
+    sb[((int64_t)c * d.Cin + ci) * T + (kd * d.KH + kh) * d.KW + kw] = red[(kw * 64 + ci) * 4 + c];
+  }
+}
+
+
+// ---- many-tap thin-output weight gradient through an LDS halo brick (sr_head's 5x5x5 16->2):
+// a block stages a 2x8x8 brick of dY and the x halo around it in LDS ONCE and every
+// (tap, channel quad) pair -- one or two per thread -- sweeps the brick from LDS, so x is read
+// from L2/HBM once per brick instead of once per tap row (25x less traffic).
+constexpr int HB_D = 2, HB_H = 8, HB_W = 8, HB_VOX = HB_D * HB_H * HB_W;
+template <int CO>
+__global__ __launch_bounds__(256) void small_cout_wgrad_halo_kernel(const rehr_direct_conv_desc d,
+                                                                    float* __restrict__ slab, int bricks_per_block,
+                                                                    int nb_d, int nb_h, int nb_w) {
+  extern __shared__ __attribute__((aligned(16))) float hl[];
+  const int HD = HB_D + d.KD - 1, HH = HB_H + d.KH - 1, HW = HB_W + d.KW - 1;
+  const int hvox = HD * HH * HW;
+  float* xs = hl;                      // [hvox][Cin]
+  float* ys = hl + hvox * d.Cin;       // [HB_VOX][CO]
+  const int T = d.KD * d.KH * d.KW, c4n = d.Cin / 4, npairs = T * c4n;
+  // up to two (tap, quad) pairs per thread
+  int tapbase[2], quad[2];
+  bool has[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int pr = threadIdx.x + 256 * k;
+    has[k] = pr < npairs;
+    const int t = has[k] ? pr / c4n : 0;
+    quad[k] = has[k] ? pr - t * c4n : 0;
+    const int kw = t % d.KW, kh = (t / d.KW) % d.KH, kd = t / (d.KW * d.KH);
+    tapbase[k] = (kd * HH + kh) * HW + kw;
+  }
+  f32x4 acc[2][CO];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t nbricks = (int64_t)d.N * nb_d * nb_h * nb_w;
+  const int64_t b0 = (int64_t)blockIdx.x * bricks_per_block;
+  for (int bi = 0; bi < bricks_per_block; ++bi) {
+    const int64_t br = b0 + bi;
+    if (br >= nbricks) break;
+    const int bw = (int)(br % nb_w);
+    int64_t r = br / nb_w;
+    const int bh = (int)(r % nb_h); r /= nb_h;
+    const int bd = (int)(r % nb_d);
+    const int n = (int)(r / nb_d);
+    const int od0 = bd * HB_D, oh0 = bh * HB_H, ow0 = bw * HB_W;
+    __syncthreads();  // previous brick fully consumed
+    // stage x halo (16-byte pieces, coalesced along channels then w)
+    const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
+    for (int i = threadIdx.x; i < hvox * c4n; i += 256) {
+      const int q = i % c4n, hv = i / c4n;
+      const int hw_ = hv % HW, hh_ = (hv / HW) % HH, hd_ = hv / (HW * HH);
+      const int id = od0 - d.pd + hd_, ih = oh0 - d.ph + hh_, iw = ow0 - d.pw + hw_;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi && (unsigned)iw < (unsigned)d.Wi)
+        v = *reinterpret_cast<const f32x4*>(xn + (((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx + q * 4);
+      *reinterpret_cast<f32x4*>(xs + hv * d.Cin + q * 4) = v;
+    }
+    for (int i = threadIdx.x; i < HB_VOX * CO; i += 256) {
+      const int c = i % CO, v = i / CO;
+      const int vw = v % HB_W, vh = (v / HB_W) % HB_H, vd = v / (HB_W * HB_H);
+      const int od = od0 + vd, oh = oh0 + vh, ow = ow0 + vw;
+      float val = 0.f;
+      if (c < d.Cout && od < d.Do && oh < d.Ho && ow < d.Wo)
+        val = d.y[((((int64_t)n * d.Do + od) * d.Ho + oh) * d.Wo + ow) * d.ldy + c];
+      ys[i] = val;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (has[k]) {
+        const float* xb = xs + tapbase[k] * d.Cin + quad[k] * 4;
+#pragma unroll 4
+        for (int v = 0; v < HB_VOX; ++v) {
+          const int vrow = ((v >> 6) * HH + ((v >> 3) & 7)) * HW + (v & 7);
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + vrow * d.Cin);
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[k][c] += xv * ys[v * CO + c];
+        }
+      }
+    }
+  }
+  float* sb = slab + (int64_t)blockIdx.x * d.Cout * d.Cin * T;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (has[k]) {
+      const int pr = threadIdx.x + 256 * k;
+      const int t = pr / c4n;
+#pragma unroll
+      for (int c = 0; c < CO; ++c)
+        if (c < d.Cout)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sb[((int64_t)c * d.Cin + quad[k] * 4 + e) * T + t] = acc[k][c][e];
+    }
+  }
+}
+
 // partial[b][c] = sum over the block's voxels of dy[.][c]
 __global__ __launch_bounds__(256) void thin_bias_partial_kernel(const float* __restrict__ dy, int ld, int C,
                                                                 int64_t rows, float* __restrict__ partial) {
@@ -609,9 +860,25 @@ bool small_cout_ok(const rehr_direct_conv_desc& d) {
     return false;
   return true;
 }
+bool sc_cg(const rehr_direct_conv_desc& d) { return d.Cin == 16 || d.Cin == 32 || d.Cin == 64; }
+bool sc_halo(const rehr_direct_conv_desc& d) {
+  const int np = d.KD * d.KH * d.KW * (d.Cin / 4);
+  const int64_t hv = (int64_t)(HB_D + d.KD - 1) * (HB_H + d.KH - 1) * (HB_W + d.KW - 1);
+  return np > 128 && np <= 512 && (hv * d.Cin + HB_VOX * 4) * 4 <= 64 * 1024;
+}
+int sc_halo_blocks(const rehr_direct_conv_desc& d, int* bpb, int* nbd, int* nbh, int* nbw) {
+  *nbd = (d.Do + HB_D - 1) / HB_D; *nbh = (d.Ho + HB_H - 1) / HB_H; *nbw = (d.Wo + HB_W - 1) / HB_W;
+  const int64_t nbricks = (int64_t)d.N * *nbd * *nbh * *nbw;
+  int64_t blocks = nbricks < 2048 ? nbricks : 2048;
+  int64_t per = (nbricks + blocks - 1) / blocks;
+  blocks = (nbricks + per - 1) / per;
+  *bpb = (int)per;
+  return (int)blocks;
+}
 int sc_strips(const rehr_direct_conv_desc& d, int* rpb) {
+  if (sc_halo(d)) { int a, b, c; return sc_halo_blocks(d, rpb, &a, &b, &c); }
   const int64_t nrows = (int64_t)d.N * d.Do * d.Ho;
-  const int64_t per_strip_blocks = (int64_t)d.KD * d.KH * (d.Cin / 4);
+  const int64_t per_strip_blocks = (int64_t)d.KD * d.KH * (sc_cg(d) ? 1 : d.Cin / 4);
   int64_t strips = (4096 + per_strip_blocks - 1) / per_strip_blocks;
   if (strips > nrows) strips = nrows;
   if (strips < 1) strips = 1;
@@ -632,10 +899,20 @@ extern "C" int rehr_conv_small_cout_fwd_f32(const rehr_direct_conv_desc* dp, voi
   const int64_t groups = (int64_t)d.N * d.Do * d.Ho * ((d.Wo + SC_VOX - 1) / SC_VOX);
   int64_t blocks = (groups + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (CO == 2)
-    hipLaunchKernelGGL(small_cout_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, d);
+  hipStream_t st = (hipStream_t)stream;
+  if (sc_cg(d)) {
+    const int cg = d.Cin / 4;
+    int64_t b2 = (groups + (256 / cg) - 1) / (256 / cg);
+    if (b2 > 16384) b2 = 16384;
+    const dim3 g((unsigned)b2), t(256);
+#define SC_FWD(CO_, CG_) hipLaunchKernelGGL((small_cout_fwd_cg_kernel<CO_, CG_>), g, t, smem, st, d)
+    if (CO == 2) { if (cg == 4) SC_FWD(2, 4); else if (cg == 8) SC_FWD(2, 8); else SC_FWD(2, 16); }
+    else         { if (cg == 4) SC_FWD(4, 4); else if (cg == 8) SC_FWD(4, 8); else SC_FWD(4, 16); }
+#undef SC_FWD
+  } else if (CO == 2)
+    hipLaunchKernelGGL(small_cout_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), smem, st, d);
   else
-    hipLaunchKernelGGL(small_cout_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(small_cout_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), smem, st, d);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -678,7 +955,25 @@ extern "C" int rehr_conv_small_cout_wgrad_f32(const rehr_direct_conv_desc* dp, f
   const int64_t blocks = (int64_t)strips * d.KD * d.KH * (d.Cin / 4);
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(workspace, 0, (size_t)strips * nw * sizeof(float), st) != hipSuccess) return REHR_EHIP;
-  if (CO == 2)
+  if (sc_halo(d)) {
+    int bpb, nbd, nbh, nbw;
+    const int hblocks = sc_halo_blocks(d, &bpb, &nbd, &nbh, &nbw);
+    const int64_t hv = (int64_t)(HB_D + d.KD - 1) * (HB_H + d.KH - 1) * (HB_W + d.KW - 1);
+    const size_t hsmem = (size_t)(hv * d.Cin + HB_VOX * CO) * sizeof(float);
+    if (CO == 2)
+      hipLaunchKernelGGL(small_cout_wgrad_halo_kernel<2>, dim3(hblocks), dim3(256), hsmem, st, d, workspace, bpb, nbd,
+                         nbh, nbw);
+    else
+      hipLaunchKernelGGL(small_cout_wgrad_halo_kernel<4>, dim3(hblocks), dim3(256), hsmem, st, d, workspace, bpb, nbd,
+                         nbh, nbw);
+  } else if (sc_cg(d)) {
+    const int cg = d.Cin / 4;
+    const dim3 g((unsigned)((int64_t)strips * d.KD * d.KH)), t(256);
+#define SC_WG(CO_, CG_) hipLaunchKernelGGL((small_cout_wgrad_cg_kernel<CO_, CG_>), g, t, 0, st, d, workspace, rpb)
+    if (CO == 2) { if (cg == 4) SC_WG(2, 4); else if (cg == 8) SC_WG(2, 8); else SC_WG(2, 16); }
+    else         { if (cg == 4) SC_WG(4, 4); else if (cg == 8) SC_WG(4, 8); else SC_WG(4, 16); }
+#undef SC_WG
+  } else if (CO == 2)
     hipLaunchKernelGGL(small_cout_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, d, workspace, rpb);
   else
     hipLaunchKernelGGL(small_cout_wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, d, workspace, rpb);

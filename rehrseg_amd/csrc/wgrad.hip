@@ -19,15 +19,12 @@
 // coordinates of a row come from multiply-high "magic" divisions, so the address
 // arithmetic of the next tile schedules into the shadow of the current MFMAs.
 #include "common.h"
+#include "wgrad_shared.h"
 
 namespace {
 
 constexpr int NTHREADS = 256;
 
-struct Magic {  // q = n / d for 0 <= n < 2^31
-  uint32_t m;
-  uint32_t sh;  // 255: d == 1
-};
 inline Magic make_magic(uint32_t d) {
   Magic g;
   if (d <= 1) { g.m = 0; g.sh = 255; return g; }
@@ -42,18 +39,6 @@ __device__ __forceinline__ uint32_t mdiv(uint32_t n, Magic g) {
   const uint32_t q = __umulhi(n, g.m) >> (g.sh & 31);
   return g.sh == 255 ? n : q;
 }
-
-struct WGParams {
-  rehr_wgrad_desc d;
-  int a_tiles, c_tiles, T;
-  int64_t kv_total;   // N * Ld*Lh*Lw
-  int64_t kv_per_split;
-  int splits;
-  int Capad, Cgpad;   // tile-padded channel counts of the slab
-  float* slab_bias;   // [splits][Ca] or null
-  Magic mg_vox, mg_hw, mg_w;
-  uint32_t g_bytes;
-};
 
 // BA x BG output tile, 4 waves as WGA x WGG x WGK (WGK waves split the K tile)
 template <int BA, int BG, int WGA, int WGG, int BKV>
@@ -389,6 +374,9 @@ extern "C" int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* dp) {
   if (!d.dst) d.dst = reinterpret_cast<float*>(16);  // size query may come before allocation
   const int rc = plan(d, p);
   if (rc != REHR_OK) return rc;
+  BrickPlanOut bo;
+  WGParams pb = p;
+  if (wgrad_brick_plan(d, pb, bo)) return ws_bytes(pb);
   return ws_bytes(p);
 }
 
@@ -397,15 +385,21 @@ extern "C" int rehr_wgrad_f32(const rehr_wgrad_desc* dp, void* stream) {
   WGParams p;
   int rc = plan(*dp, p);
   if (rc != REHR_OK) return rc;
+  BrickPlanOut bo;
+  const bool brick = wgrad_brick_plan(*dp, p, bo);  // overrides tiles / splits / slab geometry when it applies
   const rehr_wgrad_desc& d = p.d;
   if (!d.workspace || d.workspace_bytes < ws_bytes(p)) return REHR_EINVAL;
   if (p.splits > 65535) return REHR_EINVAL;
   p.slab_bias = d.dbias ? d.workspace + (int64_t)p.splits * p.T * p.Capad * p.Cgpad : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int t = p.Capad / p.a_tiles;
-  if (t == 128) rc = launch_wg<128, 2, 2, 32>(p, st);
-  else if (t == 64) rc = launch_wg<64, 1, 1, 64>(p, st);
-  else rc = launch_wg<32, 1, 1, 64>(p, st);
+  if (brick) {
+    rc = wgrad_brick_launch(p, bo, st);
+  } else {
+    const int t = p.Capad / p.a_tiles;
+    if (t == 128) rc = launch_wg<128, 2, 2, 32>(p, st);
+    else if (t == 64) rc = launch_wg<64, 1, 1, 64>(p, st);
+    else rc = launch_wg<32, 1, 1, 64>(p, st);
+  }
   if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
   int blocks = (int)((total + 255) / 256);
