@@ -23,6 +23,7 @@
 //    sum-of-squares that SEGating's pool and InstanceNorm3d need (double
 //    atomics, one per channel per wave).
 #include "common.h"
+#include "halo_conv.h"
 
 namespace {
 
@@ -383,6 +384,11 @@ extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* strea
     if (d.obd < 0 || d.obh < 0 || d.obw < 0 || yd >= d.Dy || yh >= d.Hy || yw >= d.Wy) return REHR_EINVAL;
     if (d.ldy < d.Cout) return REHR_EINVAL;
     if ((int64_t)d.N * d.Dy * d.Hy * d.Wy >= (1ll << 31)) return REHR_EINVAL;
+  }
+
+  if (d.tile_d >= 0) {  // tile_d < 0 would force the generic kernel (benchmarking)
+    const int hrc = halo_conv_try(d, (hipStream_t)stream);
+    if (hrc != REHR_ENOSUP) return hrc;
   }
 
   GGParams p;

@@ -218,10 +218,10 @@ bool wgrad_brick_plan(const rehr_wgrad_desc& d, WGParams& w, BrickPlanOut& out) 
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   const int T = d.td.count * d.th.count * d.tw.count;
   if (T < 3 || T > 4 * MAXTPW) return false;
-  if (d.Ca % 32 || d.Cg % 32) return false;
+  if (d.Ca % 4 || d.Cg % 4) return false;  // partial 32-tiles are masked (sr_head.0: 16 x 32)
   // Measured on MI355X: the brick kernel wins for thin tensors (32/64 channels: 52 -> 95 TF,
   // 90 -> 99 TF), the slab kernel's 128x128 tiles win from 128 channels up (110 vs 114 TF).
-  if ((int64_t)(d.Ca / 32) * (d.Cg / 32) > 8) return false;
+  if ((int64_t)((d.Ca + 31) / 32) * ((d.Cg + 31) / 32) > 8) return false;
   if (d.Ld < BD || d.Lh < BH || d.Lw < BW) return false;
   // padding waste of the 2x8x8 brick must stay small
   const int64_t nb_d = (d.Ld + BD - 1) / BD, nb_h = (d.Lh + BH - 1) / BH, nb_w = (d.Lw + BW - 1) / BW;
@@ -241,10 +241,10 @@ bool wgrad_brick_plan(const rehr_wgrad_desc& d, WGParams& w, BrickPlanOut& out) 
     return false;
   w.d = d;
   w.T = T;
-  w.a_tiles = d.Ca / 32;
-  w.c_tiles = d.Cg / 32;
-  w.Capad = d.Ca;
-  w.Cgpad = d.Cg;
+  w.a_tiles = (d.Ca + 31) / 32;
+  w.c_tiles = (d.Cg + 31) / 32;
+  w.Capad = w.a_tiles * 32;
+  w.Cgpad = w.c_tiles * 32;
   w.kv_total = (int64_t)d.N * d.Ld * d.Lh * d.Lw;
   out.HD = HD; out.HH = HH; out.HW = HW;
   out.mind = mn[0]; out.minh = mn[1]; out.minw = mn[2];

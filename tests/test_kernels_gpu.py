@@ -67,6 +67,37 @@ def test_conv3d(Cin, Cout, K, stride, pad, dims):
          lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, stride, pad), 0.2), [x, w, b], [True, True, True])
 
 
+HALO = [  # shapes the halo-tile kernel takes (stride 1, Cout <= 64, brick-friendly extents)
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 4, 16, 24)),
+    (32, 32, (3, 3, 3), (1, 1, 1), (2, 2, 8, 16)),
+    (96, 64, (3, 3, 3), (1, 1, 1), (1, 6, 16, 16)),
+    (16, 32, (3, 3, 3), (1, 1, 1), (1, 4, 8, 8)),
+    (32, 16, (3, 3, 3), (1, 1, 1), (1, 4, 16, 8)),
+    (32, 32, (1, 3, 3), (0, 1, 1), (2, 2, 16, 16)),
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 5, 17, 23)),   # ragged edges: masked rows
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,pad,dims", HALO)
+def test_halo_tile_conv(Cin, Cout, K, pad, dims):
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=50)
+    w = _mk(Cout, Cin, *K, seed=51) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=52)
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, pad, act=ops.ACT_RELU),
+         lambda x, w, b: torch.relu(F.conv3d(x, w, b, 1, pad)), [x, w, b], [True, True, True])
+
+
+def test_halo_tile_conv_virtual_concat_instnorm():
+    x1, x2 = _mk(2, 32, 4, 16, 16, seed=53), _mk(2, 32, 4, 16, 16, seed=54)
+    w = _mk(32, 64, 3, 3, 3, seed=55) / 41.0
+    b, ga, be = _mk(32, seed=56), _mk(32, seed=57), _mk(32, seed=58)
+    _run(lambda a, c, w, b, ga, be: ops.fused_conv3d(a, w, b, 1, 1, x2=c, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
+         lambda a, c, w, b, ga, be: F.leaky_relu(
+             F.instance_norm(F.conv3d(torch.cat([a, c], 1), w, b, 1, 1), weight=ga, bias=be), 0.01),
+         [x1, x2, w, b, ga, be], [True, True, True, False, True, True])
+
+
 TCONVS = [
     (128, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (1, 4, 9, 10)),
     (64, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 3, 5, 6)),
