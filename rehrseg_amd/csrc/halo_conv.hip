@@ -126,19 +126,28 @@ __global__ __launch_bounds__(256, 2) void halo_conv_kernel(const HaloParams p) {
   };
 
   const int ntaps = d.td.count * d.th.count * d.tw.count;
-  auto tap_geom = [&](int t, int& tapoff, int& wt) {
-    const int jw = t % d.tw.count;
-    const int t2 = t / d.tw.count;
-    const int jh = t2 % d.th.count, jd = t2 / d.th.count;
+  // tap iterator: (jd, jh, jw) counters advanced without divisions (all wave-uniform scalars)
+  int jd = 0, jh = 0, jw = 0;
+  auto tap_geom = [&](int& tapoff, int& wt) {
     const int od_ = d.bd + d.td.off0 + d.td.offs * jd - p.mind;
     const int oh_ = d.bh + d.th.off0 + d.th.offs * jh - p.minh;
     const int ow_ = d.bw + d.tw.off0 + d.tw.offs * jw - p.minw;
     tapoff = ((od_ * p.HH + oh_) * p.HW + ow_) * LDX;
     wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW + (d.tw.k0 + d.tw.ks * jw);
+    // advance; after the last tap the counters wrap to tap 0 (that prefetch is never used)
+    ++jw;
+    const bool cw = jw >= d.tw.count;
+    jw = cw ? 0 : jw;
+    jh += cw ? 1 : 0;
+    const bool ch = jh >= d.th.count;
+    jh = ch ? 0 : jh;
+    jd += ch ? 1 : 0;
+    jd = jd >= d.td.count ? 0 : jd;
   };
-  auto mfma_tap = [&](int tapoff, const f32x4 (&rb)[FN][4]) {
+  auto mfma_tap = [&](int tapoff, const f32x4 (&rb)[FN][4], int kgroups) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+      if (kk >= kgroups) break;  // half-filled last chunk (Cin % 32 == 16): skip the zero k-groups
       f32x4 fa[FM];
 #pragma unroll
       for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Xs + arow[i] + tapoff + kk * 8);
@@ -171,22 +180,22 @@ __global__ __launch_bounds__(256, 2) void halo_conv_kernel(const HaloParams p) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
     fetch(it + 1);  // next halo: in flight during this sweep
+    const int kgroups = (d.Cin - cc) >= 32 ? 4 : (d.Cin - cc) / 8;
 
     // taps, weights one tap ahead (two named register sets)
     f32x4 rb0[FN][4], rb1[FN][4];
     int off0, wt0, off1, wt1;
-    tap_geom(0, off0, wt0);
+    jd = jh = jw = 0;
+    tap_geom(off0, wt0);
     load_b(wt0, cc, rb0);
     for (int t = 0; t < ntaps; t += 2) {
-      const int tn = (t + 1 < ntaps) ? t + 1 : t;
-      tap_geom(tn, off1, wt1);
+      tap_geom(off1, wt1);          // tap t+1 (wraps harmlessly past the end)
       load_b(wt1, cc, rb1);
-      mfma_tap(off0, rb0);
+      mfma_tap(off0, rb0, kgroups);
       if (t + 1 >= ntaps) break;
-      const int tnn = (t + 2 < ntaps) ? t + 2 : t + 1;
-      tap_geom(tnn, off0, wt0);
+      tap_geom(off0, wt0);          // tap t+2
       load_b(wt0, cc, rb0);
-      mfma_tap(off1, rb1);
+      mfma_tap(off1, rb1, kgroups);
     }
 
     if (chunk == p.kchunks - 1) {
