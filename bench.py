@@ -165,9 +165,16 @@ def main():
         gg = prof.get("gather_gemm")
         if gg:
             ach = gg["flops"] / gg["seconds"] / 1e12
+            # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
+            # (FETCH_SIZE / WRITE_SIZE cannot share a pass); the committed summary is read back here.
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if args.workload == "flavr" and size == 128 and os.path.exists(tp):
+                traffic = json.load(open(tp))["kernels"].get("gather_gemm<128,128>", {}).get("hbm_bytes_per_launch")
             rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "gather_gemm_kernel (fp32 MFMA implicit GEMM: conv fwd/dgrad, convT fwd/dgrad)",
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                               "kernel": "gather-GEMM family (gather_gemm_kernel + halo_conv_kernel: fp32 MFMA implicit "
+                                         "GEMM for conv fwd/dgrad, convT fwd/dgrad)",
                                "launches_per_step": gg["launches"] / args.steps,
                                "avg_launch_ms": gg["seconds"] / gg["launches"] * 1e3,
                                "algorithmic_gflop_per_step": gg["flops"] / args.steps / 1e9}
