@@ -43,6 +43,19 @@ def build_seg_model(dev):
                     nonlin=nn.LeakyReLU, nonlin_kwargs={"inplace": True}, deep_supervision=False).to(dev)
 
 
+class _Opt:
+    """optimizer facade whose zero_grad keeps PatchParallel's flat gradient views"""
+
+    def __init__(self, opt, pp):
+        self.opt, self.pp = opt, pp
+
+    def zero_grad(self):
+        self.pp.zero_grad()
+
+    def step(self):
+        self.opt.step()
+
+
 def cpu_baseline(size):
     """The oracle (a CPU port of the reference's path) on the host cores, one step."""
     from oracle import flavr_oracle as fo
@@ -70,8 +83,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=128, help="patch edge (128 = BASELINE config)")
-    ap.add_argument("--workload", choices=["flavr", "seg"], default="flavr",
-                    help="flavr = configs[1] (headline); seg = configs[2] (SegModel 2x1x128^3, secondary)")
+    ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref"], default="flavr",
+                    help="flavr = configs[1] (headline); seg = configs[2] (SegModel 2x1x128^3, secondary); "
+                         "flavr_ref = the reference's own stage-1 training shape, UNet_3D_3D(2,..,4,4) on "
+                         "(B,2,4,96,96) with the UASR head (configs/brain.yaml)")
+    ap.add_argument("--batch", type=int, default=32, help="batch of the flavr_ref workload (brain.yaml: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -110,6 +126,27 @@ def main():
             pp.reduce_gradients()
             opt.step()
             return loss
+    elif args.workload == "flavr_ref":
+        from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+        from rehrseg_amd.train_steps import train_sr_step
+        from rehrseg_amd.utils.seg_utils import BCEDiceLoss
+        torch.manual_seed(0)
+        model = UNet_3D_3D(2, "unet_18", 4, 4, use_uncertainty=True).to(dev)
+        pp = PatchParallel(model)
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.99), fused=True)
+        B = args.batch
+        x = torch.rand(B, 2, 4, 96, 96, generator=g).to(dev)
+        hr = torch.rand(B, 2, 16, 96, 96, generator=g)
+        hr[:, 1:] = (hr[:, 1:] > 0.5).float()
+        hr = hr.to(dev)
+        patches_per_step = B
+        workload = (f"FLAVR UNet_3D_3D(2,'unet_18',4,4,use_uncertainty) train_sr step (L1 + UASR terms + BCEDice + Adam), "
+                    f"{B}x2x4x96x96 per GPU, random-init weights")
+        l1, bd = torch.nn.L1Loss(), BCEDiceLoss(1.0, 1.0)
+
+        def step():
+            return train_sr_step(model, _Opt(opt, pp), None, x.clone(), hr, l1, bd, 4.0, 4, True,
+                                 grad_sync=pp.reduce_gradients)
     else:
         model = build_seg_model(dev)
         pp = PatchParallel(model)

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void halo_conv_kernel(const HaloParams p) {
       if (tid < BVOX) {
         const int od = bd_ * BD + (tid >> 6), oh = bh_ * BH + ((tid >> 3) & 7), ow = bw_ * BW + (tid & 7);
         int off = -1;
-        if (od < d.Ld && oh < d.Lh && ow < d.Lw) off = ((n_img * d.Dy + od) * d.Hy + oh) * d.Wy + ow;
+        if (od < d.Ld && oh < d.Lh && ow < d.Lw)
+          off = ((n_img * d.Dy + od * d.osd + d.obd) * d.Hy + oh * d.osh + d.obh) * d.Wy + ow * d.osw + d.obw;
         row_out[tid] = off;
       }
       __syncthreads();
@@ -283,8 +284,6 @@ int launch(const HaloParams& p, size_t smem, hipStream_t stream) {
 // REHR_ENOSUP = "not this kernel's case" (the caller then uses the generic gather-GEMM).
 int halo_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return REHR_ENOSUP;
-  if (d.osd != 1 || d.osh != 1 || d.osw != 1 || d.obd || d.obh || d.obw) return REHR_ENOSUP;
-  if (d.Ld != d.Dy || d.Lh != d.Hy || d.Lw != d.Wy) return REHR_ENOSUP;
   if (d.Npad > 64) return REHR_ENOSUP;
   const int T = d.td.count * d.th.count * d.tw.count;
   if (T < 9 || T > 64) return REHR_ENOSUP;   // few taps: the gather kernel is already cheap per byte

@@ -4,9 +4,13 @@
 ONE exchange per step over RCCL/xGMI (torch.distributed backend "nccl").
 
 Gradients live in a single flat fp32 buffer (`.grad` of every parameter is a view
-into it), so the exchange is a handful of large all-reduces (default 64 MiB
-buckets: xGMI is point-to-point, per-link bound, so few large messages beat many
-small ones) with no flatten/unflatten copies.
+into it), laid out in REVERSE registration order: backward produces the decoder's
+gradients first, so the front of the buffer completes first.  The buffer is cut into
+a few large buckets (default 64 MiB: xGMI is point-to-point and per-link bound, so
+few large messages beat many small ones); a bucket's all-reduce is launched from a
+post-accumulate hook the moment its last gradient has been written, i.e. the exchange
+of the decoder's gradients overlaps the encoder's backward.  No flatten/unflatten
+copies, no per-parameter messages.
 """
 from __future__ import annotations
 
@@ -15,7 +19,7 @@ import torch.distributed as dist
 
 
 class PatchParallel:
-    def __init__(self, module: torch.nn.Module, bucket_mb: int = 64, process_group=None):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 64, process_group=None, overlap: bool = True):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -25,32 +29,65 @@ class PatchParallel:
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
+        bucket_elems = max(1, int(bucket_mb * (1 << 20)) // self.flat.element_size())
+        # reverse registration order ~ the order in which backward finishes the gradients
+        self._bucket_of = {}
+        self.buckets = []  # [start, end, n_params]
         off = 0
-        for p in self.params:
+        for p in reversed(self.params):
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            if not self.buckets or off - self.buckets[-1][0] >= bucket_elems:
+                self.buckets.append([off, off + n, 0])
+            b = self.buckets[-1]
+            b[1] = off + n
+            b[2] += 1
+            self._bucket_of[p] = len(self.buckets) - 1
             off += n
-        self.bucket_elems = max(1, (bucket_mb << 20) // self.flat.element_size())
+        self.overlap = overlap and self.world > 1
+        self._pending = [b[2] for b in self.buckets]
+        self._works = []
+        self._launched = [False] * len(self.buckets)
+        if self.overlap:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad_ready)
         if self.world > 1:
             for p in module.parameters():  # identical starting point on every rank
                 dist.broadcast(p.data, src=0, group=process_group)
             for b in module.buffers():
                 dist.broadcast(b.data, src=0, group=process_group)
 
+    # ------------------------------------------------------------------ bucket exchange
+    def _launch(self, i):
+        s, e, _ = self.buckets[i]
+        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched[i] = True
+
+    def _on_grad_ready(self, p):
+        i = self._bucket_of[p]
+        self._pending[i] -= 1
+        if self._pending[i] == 0 and not self._launched[i]:
+            self._launch(i)
+
     def zero_grad(self):
         """Keeps the .grad views (optimizer.zero_grad(set_to_none=True) would drop them)."""
         self.flat.zero_()
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
 
     def reduce_gradients(self):
-        """Sum over ranks, divide by world size; returns after the exchange completed."""
+        """Sum over ranks, divide by world size; returns after the exchange completed.
+        Buckets whose hooks did not fire (parameters without a gradient this step, or
+        overlap disabled) are exchanged here."""
         if self.world == 1:
             return
-        works = []
-        for s in range(0, self.flat.numel(), self.bucket_elems):
-            works.append(dist.all_reduce(self.flat[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group,
-                                         async_op=True))
-        for w in works:
+        for i in range(len(self.buckets)):
+            if not self._launched[i]:
+                self._launch(i)
+        for w in self._works:
             w.wait()
+        self._works = []
         self.flat.div_(self.world)
 
     def grad_bytes(self):

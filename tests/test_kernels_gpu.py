@@ -102,6 +102,8 @@ TCONVS = [
     (128, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (1, 4, 9, 10)),
     (64, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 3, 5, 6)),
     (320, 320, (1, 2, 2), (1, 2, 2), (0, 0, 0), (1, 4, 4, 4)),
+    (64, 32, (3, 4, 4), (1, 2, 2), (1, 1, 1), (1, 4, 16, 16)),   # stride phases through the halo-tile kernel
+    (128, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (2, 2, 8, 24)),
 ]
 
 

@@ -20,8 +20,8 @@ def _worker(rank, world, port, q):
     from rehrseg_amd.parallel import PatchParallel
     torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
-    pp = PatchParallel(model, bucket_mb=1)
-    pp.bucket_elems = 7  # force several buckets
+    pp = PatchParallel(model, bucket_mb=3e-5)  # ~7 elements per bucket: several buckets, launched from hooks
+    assert len(pp.buckets) >= 2 and pp.overlap
     w0 = torch.cat([p.detach().flatten() for p in model.parameters()])
     torch.manual_seed(7 + rank)  # every rank draws its own "patch"
     x = torch.randn(4, 6)
@@ -58,7 +58,7 @@ def test_patch_parallel_gloo_world2():
     for x in (xa, xb):
         model.zero_grad()
         model(x).square().mean().backward()
-        gs.append(torch.cat([p.grad.flatten() for p in model.parameters()]))
+        gs.append(torch.cat([p.grad.flatten() for p in reversed(list(model.parameters()))]))  # flat buffer order
     assert torch.allclose(ga[0], (gs[0] + gs[1]) / 2, atol=1e-6)
     assert torch.allclose(ga[1], ga[0], atol=1e-7)     # zero_grad keeps the views; step 2 == step 1
 
@@ -70,4 +70,5 @@ def test_single_process_is_a_noop_reduce():
     m(torch.ones(1, 3)).sum().backward()
     before = pp.flat.clone()
     pp.reduce_gradients()
-    assert torch.equal(before, pp.flat) and m.weight.grad.data_ptr() == pp.flat.data_ptr()
+    assert torch.equal(before, pp.flat)
+    assert m.bias.grad.data_ptr() == pp.flat.data_ptr()  # reverse registration order: the last parameter comes first
