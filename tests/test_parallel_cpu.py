@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
         model(x).square().mean().backward()
         pp.reduce_gradients()
         outs.append(pp.flat.clone())
-    q.put((rank, w0, x, outs))
+    q.put((rank, w0.numpy(), x.numpy(), [o.numpy() for o in outs]))  # plain arrays: no shared-memory handles
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,6 +47,7 @@ def test_patch_parallel_gloo_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    res = [(r, torch.from_numpy(w), torch.from_numpy(x), [torch.from_numpy(o) for o in g]) for r, w, x, g in res]
     (_, w0a, xa, ga), (_, w0b, xb, gb) = res
     assert torch.equal(w0a, w0b)                      # parameters were broadcast from rank 0
     for a, b in zip(ga, gb):
