@@ -95,7 +95,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    launched = "TORCHELASTIC_RUN_ID" in os.environ  # started by torch.distributed.run (also with one rank)
+    if args.gpus > 1 or world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
@@ -170,7 +171,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_kernel_timing:
@@ -179,11 +180,11 @@ def main():
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = hip_backend.profile_stop() if not args.no_kernel_timing else {}
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -227,7 +228,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "flavr":
             rec["cpu_baseline"] = cpu_baseline(size)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
