@@ -95,6 +95,10 @@ typedef struct {
 } rehr_gather_gemm_desc;
 
 int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);
+/* The stride phases of ONE layer (same x1/x2, wp, y, N, Npad; count <= 8), differing
+ * only in lattice, taps and destination offset, in a single grid.                   */
+int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, int32_t count,
+                               void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Weight gradient (Conv3d.weight.grad / ConvTranspose3d.weight.grad):

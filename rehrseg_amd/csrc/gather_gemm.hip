@@ -44,7 +44,7 @@ struct GGParams {
 //             halves LDS so the narrow-N tiles run 3 blocks per CU, whose MFMA phases fill each
 //             other's barrier bubbles.
 template <int BM, int BN, int WGM, int WGN, int LDSBUF>
-__global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_kernel(const GGParams p) {
+__device__ __forceinline__ void gather_gemm_body(const GGParams& p, const int nblocks) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int FM = WTM / 32, FN = WTN / 32;
   constexpr int AROWS = BM / 32, BROWS = BN / 32;  // rows per thread per tile
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_k
   const int wm = wave / WGN, wn = wave % WGN;
   const int n_img = blockIdx.y;
 
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = xcd_remap(blockIdx.x, nblocks);
   const int mt = logical / p.n_tiles;
   const int nt = logical - mt * p.n_tiles;
   const int n0 = nt * BN;
@@ -338,30 +338,60 @@ __global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_k
   }
 }
 
+constexpr int MAX_PHASES = 8;
+// Several launches that differ only in lattice / taps / destination offset (the stride
+// phases of one transposed conv or strided input gradient) share ONE grid: blockIdx.z picks
+// the phase, so four quarter-size launches fill the chip like one full-size launch.
+struct GGMulti {
+  GGParams ph[MAX_PHASES];
+};
+
 template <int BM, int BN, int WGM, int WGN, int LDSBUF>
-int launch_gg(const GGParams& p, hipStream_t stream) {
+__global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_multi_kernel(const GGMulti pm) {
+  const GGParams& p = pm.ph[blockIdx.z];
+  const int nb = p.m_tiles * p.n_tiles;
+  if ((int)blockIdx.x >= nb) return;  // block-uniform: phases have different tile counts
+  gather_gemm_body<BM, BN, WGM, WGN, LDSBUF>(p, nb);
+}
+// single launch: parameters at fixed kernarg offsets (the dynamically indexed form above costs
+// a few VGPR spills in the register-tight 128x128 tile)
+template <int BM, int BN, int WGM, int WGN, int LDSBUF>
+__global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_kernel(const GGParams p) {
+  gather_gemm_body<BM, BN, WGM, WGN, LDSBUF>(p, (int)gridDim.x);
+}
+
+template <int BM, int BN, int WGM, int WGN, int LDSBUF>
+int launch_gg(const GGMulti& pm, int count, hipStream_t stream) {
   const size_t smem = (size_t)LDSBUF * (BM + BN) * LDS_LD * sizeof(float) + BM * sizeof(int);
   static bool attr_set = false;
-  auto kern = gather_gemm_kernel<BM, BN, WGM, WGN, LDSBUF>;
+  auto kern1 = gather_gemm_kernel<BM, BN, WGM, WGN, LDSBUF>;
+  auto kernm = gather_gemm_multi_kernel<BM, BN, WGM, WGN, LDSBUF>;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
       return REHR_EHIP;
     attr_set = true;
   }
-  dim3 grid(p.m_tiles * p.n_tiles, p.d.N, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, stream, p);
+  if (count == 1) {
+    const GGParams& p = pm.ph[0];
+    hipLaunchKernelGGL(kern1, dim3(p.m_tiles * p.n_tiles, p.d.N, 1), dim3(NTHREADS), smem, stream, p);
+  } else {
+    int nb = 0;
+    for (int i = 0; i < count; ++i) {
+      const int n = pm.ph[i].m_tiles * pm.ph[i].n_tiles;
+      nb = n > nb ? n : nb;
+    }
+    hipLaunchKernelGGL(kernm, dim3(nb, pm.ph[0].d.N, count), dim3(NTHREADS), smem, stream, pm);
+  }
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
 
 bool taps_ok(const rehr_axis_taps& t) { return t.count >= 1; }
 
-}  // namespace
-
-extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* stream) {
-  if (dp == nullptr) return REHR_EINVAL;
-  const rehr_gather_gemm_desc& d = *dp;
+int validate(const rehr_gather_gemm_desc& d) {
   if (!d.x1 || !d.wp || !d.y) return REHR_EINVAL;
   if (d.N < 1 || d.Cin < 16 || d.Cin % 16 || d.c1 < 0 || d.c1 > d.Cin) return REHR_EINVAL;
   if (d.c1 < d.Cin && d.c1 % 32) return REHR_EINVAL;  // a virtual concat splits on a chunk boundary
@@ -378,20 +408,15 @@ extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* strea
   if (d.stats_mode != 0 && !d.stats) return REHR_EINVAL;
   if (d.N > 65535) return REHR_EINVAL;
   // destination extent check: the last lattice point must land inside y
-  {
-    const int64_t yd = (int64_t)(d.Ld - 1) * d.osd + d.obd, yh = (int64_t)(d.Lh - 1) * d.osh + d.obh,
-                  yw = (int64_t)(d.Lw - 1) * d.osw + d.obw;
-    if (d.obd < 0 || d.obh < 0 || d.obw < 0 || yd >= d.Dy || yh >= d.Hy || yw >= d.Wy) return REHR_EINVAL;
-    if (d.ldy < d.Cout) return REHR_EINVAL;
-    if ((int64_t)d.N * d.Dy * d.Hy * d.Wy >= (1ll << 31)) return REHR_EINVAL;
-  }
+  const int64_t yd = (int64_t)(d.Ld - 1) * d.osd + d.obd, yh = (int64_t)(d.Lh - 1) * d.osh + d.obh,
+                yw = (int64_t)(d.Lw - 1) * d.osw + d.obw;
+  if (d.obd < 0 || d.obh < 0 || d.obw < 0 || yd >= d.Dy || yh >= d.Hy || yw >= d.Wy) return REHR_EINVAL;
+  if (d.ldy < d.Cout) return REHR_EINVAL;
+  if ((int64_t)d.N * d.Dy * d.Hy * d.Wy >= (1ll << 31)) return REHR_EINVAL;
+  return REHR_OK;
+}
 
-  if (d.tile_d >= 0) {  // tile_d < 0 would force the generic kernel (benchmarking)
-    const int hrc = halo_conv_try(d, (hipStream_t)stream);
-    if (hrc != REHR_ENOSUP) return hrc;
-  }
-
-  GGParams p;
+int plan(const rehr_gather_gemm_desc& d, GGParams& p) {
   p.d = d;
   if (d.tile_d == 0) {
     p.tiles_d = p.tiles_h = 1;
@@ -404,27 +429,57 @@ extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* strea
     p.m_tiles = p.tiles_d * p.tiles_h * p.tiles_w;
   }
   p.kchunks = (d.Cin + 31) / 32;
-  {
-    // buffer-addressed operands: 32-bit byte offsets per sample / per weight panel
-    const int64_t kd_max = d.td.k0 + (int64_t)d.td.ks * (d.td.count - 1);
-    const int64_t kh_max = d.th.k0 + (int64_t)d.th.ks * (d.th.count - 1);
-    const int64_t kw_max = d.tw.k0 + (int64_t)d.tw.ks * (d.tw.count - 1);
-    const int64_t taps_all = ((kd_max * d.KH) + kh_max) * d.KW + kw_max + 1;
-    p.wp_bytes = taps_all * d.Npad * d.Cin * 4;
-    const int64_t img = (int64_t)d.Di * d.Hi * d.Wi * 4;
-    if (p.wp_bytes >= (1ll << 32) - 64 || img * d.ldx1 >= (1ll << 32) - 64 ||
-        (d.x2 && img * d.ldx2 >= (1ll << 32) - 64))
-      return REHR_ENOSUP;
+  // buffer-addressed operands: 32-bit byte offsets per sample / per weight panel
+  const int64_t kd_max = d.td.k0 + (int64_t)d.td.ks * (d.td.count - 1);
+  const int64_t kh_max = d.th.k0 + (int64_t)d.th.ks * (d.th.count - 1);
+  const int64_t kw_max = d.tw.k0 + (int64_t)d.tw.ks * (d.tw.count - 1);
+  const int64_t taps_all = ((kd_max * d.KH) + kh_max) * d.KW + kw_max + 1;
+  p.wp_bytes = taps_all * d.Npad * d.Cin * 4;
+  const int64_t img = (int64_t)d.Di * d.Hi * d.Wi * 4;
+  if (p.wp_bytes >= (1ll << 32) - 64 || img * d.ldx1 >= (1ll << 32) - 64 ||
+      (d.x2 && img * d.ldx2 >= (1ll << 32) - 64))
+    return REHR_ENOSUP;
+  p.n_tiles = d.Npad / (d.Npad % 128 == 0 ? 128 : (d.Npad % 64 == 0 ? 64 : 32));
+  return REHR_OK;
+}
+
+int launch_generic(const GGMulti& pm, int count, hipStream_t st) {
+  const int npad = pm.ph[0].d.Npad;
+  if (npad % 128 == 0) return launch_gg<128, 128, 2, 2, 2>(pm, count, st);
+  if (npad % 64 == 0) return launch_gg<128, 64, 2, 2, 1>(pm, count, st);
+  return launch_gg<128, 32, 4, 1, 1>(pm, count, st);
+}
+
+}  // namespace
+
+extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, int32_t count, void* stream) {
+  if (descs == nullptr || count < 1 || count > MAX_PHASES) return REHR_EINVAL;
+  for (int i = 0; i < count; ++i) {
+    const int rc = validate(descs[i]);
+    if (rc != REHR_OK) return rc;
+    // phases of one layer: same operands and channel geometry
+    if (descs[i].Npad != descs[0].Npad || descs[i].N != descs[0].N || descs[i].wp != descs[0].wp ||
+        descs[i].x1 != descs[0].x1 || descs[i].y != descs[0].y)
+      return REHR_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (d.Npad % 128 == 0) {
-    p.n_tiles = d.Npad / 128;
-    return launch_gg<128, 128, 2, 2, 2>(p, st);
-  } else if (d.Npad % 64 == 0) {
-    p.n_tiles = d.Npad / 64;
-    return launch_gg<128, 64, 2, 2, 1>(p, st);
-  } else {
-    p.n_tiles = d.Npad / 32;
-    return launch_gg<128, 32, 4, 1, 1>(p, st);
+  GGMulti pm;
+  int n = 0;
+  for (int i = 0; i < count; ++i) {
+    if (descs[i].tile_d >= 0) {  // the halo-tile kernel takes what it is good at, one launch each
+      const int hrc = halo_conv_try(descs[i], st);
+      if (hrc == REHR_OK) continue;
+      if (hrc != REHR_ENOSUP) return hrc;
+    }
+    const int rc = plan(descs[i], pm.ph[n]);
+    if (rc != REHR_OK) return rc;
+    ++n;
   }
+  if (n == 0) return REHR_OK;
+  return launch_generic(pm, n, st);
+}
+
+extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* stream) {
+  if (dp == nullptr) return REHR_EINVAL;
+  return rehr_gather_gemm_multi_f32(dp, 1, stream);
 }

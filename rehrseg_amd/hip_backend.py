@@ -116,10 +116,9 @@ def pack_weights(w, A, Apad, B, T, transpose):
     return out
 
 
-def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
-                os_, ob, bias, act, slope, stats, stats_mode, tile):
+def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
+             os_, ob, bias, act, slope, stats, stats_mode, tile):
     _chk_dev(x1, x2, wp, y, bias, stats)
-    d = L.GatherGemmDesc()
     d.x1, d.x2, d.c1 = _ptr(x1), _ptr(x2), c1
     d.ldx1 = x1.shape[1]
     d.ldx2 = x2.shape[1] if x2 is not None else 0
@@ -140,9 +139,24 @@ def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d.bias, d.act, d.slope = _ptr(bias), act, slope
     d.stats, d.stats_mode = _ptr(stats), stats_mode
     d.tile_d, d.tile_h, d.tile_w = tile
-    flops = _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
+    return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
+
+
+def gather_gemm(*args):
+    d = L.GatherGemmDesc()
+    flops = _gg_desc(d, *args)
     with _timed("gather_gemm", flops):
         L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
+
+
+def gather_gemm_multi(calls):
+    """`calls` = argument tuples of gather_gemm for the stride phases of one layer: one grid."""
+    if len(calls) == 1:
+        return gather_gemm(*calls[0])
+    arr = (L.GatherGemmDesc * len(calls))()
+    flops = sum(_gg_desc(arr[i], *a) for i, a in enumerate(calls))
+    with _timed("gather_gemm", flops):
+        L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 
 
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):

@@ -78,6 +78,7 @@ _P_GG, _P_WG, _P_DC = C.POINTER(GatherGemmDesc), C.POINTER(WgradDesc), C.POINTER
 # name -> (restype, argtypes); must list every function include/rehrseg_hip.h declares
 PROTOTYPES = {
     "rehr_gather_gemm_f32": (C.c_int, [_P_GG, _vp]),
+    "rehr_gather_gemm_multi_f32": (C.c_int, [_P_GG, _i32, _vp]),
     "rehr_wgrad_workspace_bytes": (_i64, [_P_WG]),
     "rehr_wgrad_f32": (C.c_int, [_P_WG, _vp]),
     "rehr_pack_weights_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -157,6 +157,7 @@ def _phased_gather(src1, src2, c1, Csrc, wp, Npad, dst, Cdst, K, stride, pad, bi
     ConvTranspose3d forward)."""
     be = get_backend()
     src_dims, dst_dims = _spatial(src1), _spatial(dst)
+    calls = []
     for ph in itertools.product(*(range(s) for s in stride)):
         taps = [phase_taps(K[a], stride[a], pad[a], ph[a]) for a in range(3)]
         lattice = tuple((dst_dims[a] - ph[a] + stride[a] - 1) // stride[a] for a in range(3))
@@ -165,9 +166,11 @@ def _phased_gather(src1, src2, c1, Csrc, wp, Npad, dst, Cdst, K, stride, pad, bi
         if any(t is None for t in taps):
             continue  # no tap reaches this phase: dst keeps its zero fill
         thin = tuple(src_dims[a] == 1 and taps[a][0] > 1 for a in range(3))
-        be.gather_gemm(src1, src2, c1, src_dims, Csrc, lattice, (1, 1, 1), (0, 0, 0), taps, K[1], K[2], wp, Npad,
-                       dst, dst_dims, Cdst, stride, ph, bias, act, slope, stats, stats_mode,
-                       choose_tile(tuple(lattice), thin))
+        calls.append((src1, src2, c1, src_dims, Csrc, lattice, (1, 1, 1), (0, 0, 0), taps, K[1], K[2], wp, Npad,
+                      dst, dst_dims, Cdst, stride, ph, bias, act, slope, stats, stats_mode,
+                      choose_tile(tuple(lattice), thin)))
+    if calls:
+        be.gather_gemm_multi(calls)  # all phases of the layer in one grid
 
 
 def _has_empty_phase(K, stride, pad):

@@ -87,6 +87,13 @@ def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             stats[:, :, 1] += (acc.double() ** 2).sum((2, 3, 4))
 
 
+def gather_gemm_multi(calls):
+    assert 1 <= len(calls) <= 8
+    for a in calls:
+        assert a[0] is calls[0][0] and a[11] is calls[0][11] and a[13] is calls[0][13]  # same x1 / wp / y
+        gather_gemm(*a)
+
+
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):
     assert Ca % 4 == 0 and Cg % 4 == 0 and tuple(l.shape[2:]) == tuple(lattice)
     flat = dst.view(-1)
