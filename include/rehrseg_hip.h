@@ -99,6 +99,14 @@ int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);
  * only in lattice, taps and destination offset, in a single grid.                   */
 int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, int32_t count,
                                void* stream);
+/* Split-K combine: y[row][c] = act(bias[c] + sum_s slabs[s*slab_stride + row*C + c]).
+ * A contraction with few lattice tiles and very many taps (feature_fuse:
+ * models/FLAVR/FLAVR_arch.py:145, 16384 voxels x 1152 taps) is launched as S
+ * tap ranges writing S dense slabs through rehr_gather_gemm_multi_f32 (descs that
+ * differ in y), then combined here in a fixed order.                            */
+int rehr_sum_slabs_bias_act_f32(const float* slabs, int32_t S, int64_t slab_stride,
+                                const float* bias, float* y, int64_t rows, int32_t C,
+                                int32_t act, float slope, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Weight gradient (Conv3d.weight.grad / ConvTranspose3d.weight.grad):

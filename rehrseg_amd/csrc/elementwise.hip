@@ -670,3 +670,36 @@ extern "C" int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
+
+// ---------------------------------------------------------------- split-K combine
+// y[row][c] = act(bias[c] + sum_s slabs[s][row][c])   (few-tile, many-tap contractions
+// such as feature_fuse run as S partial launches over tap ranges; fixed summation order)
+namespace {
+__global__ void sum_slabs_bias_act_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,
+                                          const float* __restrict__ bias, float* __restrict__ y, int64_t rows,
+                                          int C, int act, float slope) {
+  const int c4n = C >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) v = *reinterpret_cast<const f32x4*>(bias + c);
+    for (int s = 0; s < S; ++s) v += reinterpret_cast<const f32x4*>(slabs + s * slab_stride)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int rehr_sum_slabs_bias_act_f32(const float* slabs, int32_t S, int64_t slab_stride, const float* bias,
+                                           float* y, int64_t rows, int32_t C, int32_t act, float slope,
+                                           void* stream) {
+  if (!slabs || !y || S < 1 || rows < 1 || C < 4 || C % 4 || slab_stride < rows * C || slab_stride % 4) return REHR_EINVAL;
+  if ((((uintptr_t)slabs) | ((uintptr_t)y)) & 15) return REHR_EINVAL;
+  hipLaunchKernelGGL(sum_slabs_bias_act_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, slabs, S, slab_stride, bias, y, rows, C, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}

@@ -459,8 +459,8 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
     if (rc != REHR_OK) return rc;
     // phases of one layer: same operands and channel geometry
     if (descs[i].Npad != descs[0].Npad || descs[i].N != descs[0].N || descs[i].wp != descs[0].wp ||
-        descs[i].x1 != descs[0].x1 || descs[i].y != descs[0].y)
-      return REHR_EINVAL;
+        descs[i].x1 != descs[0].x1)
+      return REHR_EINVAL;  // (y may differ: split-K partials go to separate slabs)
   }
   hipStream_t st = (hipStream_t)stream;
   GGMulti pm;

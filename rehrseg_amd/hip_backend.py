@@ -159,6 +159,18 @@ def gather_gemm_multi(calls):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 
 
+def sum_slabs_bias_act(slabs, S, bias, act, slope):
+    """slabs: (S*N, C, D, H, W) NDHWC partial results -> (N, C, D, H, W) = act(bias + sum over S)."""
+    _chk_dev(slabs, bias)
+    SN, Cc, D, H, W = slabs.shape
+    N = SN // S
+    y = new_act(N, Cc, D, H, W, like=slabs)
+    rows = N * D * H * W
+    L.check(L.load().rehr_sum_slabs_bias_act_f32(_ptr(slabs), S, rows * Cc, _ptr(bias), _ptr(y), rows, Cc, act, slope,
+                                                 _stream()), "rehr_sum_slabs_bias_act_f32")
+    return y
+
+
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):
     _chk_dev(l, g, dst, dbias)
     d = L.WgradDesc()

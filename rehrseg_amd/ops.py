@@ -217,9 +217,25 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
         _phased_gather(x1, x2, c1, Cin, wp, Npad, y, Cout, K, cfg.stride, cfg.pad, bias, act, slope, stats,
                        stats_mode)
         return y, stats
-    y = be.new_act(N, Cout, *out_dims, like=x1)
     wp, Npad = _pack(w, 0)
     taps = [full_taps(k) for k in K]
+    # Few lattice tiles but a very long K (feature_fuse: 128 tiles x 1152 taps): split the depth
+    # taps over S partial launches in one grid and combine the slabs in a fixed order.
+    ovox = out_dims[0] * out_dims[1] * out_dims[2]
+    blocks = -(-ovox // 128) * (Npad // (128 if Npad % 128 == 0 else (64 if Npad % 64 == 0 else 32))) * N
+    if blocks < 256 and K[0] >= 16 and stats_mode == 0 and Cout % 4 == 0:
+        S = min(8, max(2, 512 // blocks))
+        slabs = be.new_act(S * N, Cout, *out_dims, like=x1)
+        calls, step = [], -(-K[0] // S)
+        for s_i in range(S):
+            a, b_ = s_i * step, min(K[0], (s_i + 1) * step)
+            tp = [(b_ - a, a, 1, a, 1), taps[1], taps[2]]
+            calls.append((x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), tp, K[1], K[2],
+                          wp, Npad, slabs[s_i * N:(s_i + 1) * N], out_dims, Cout, (1, 1, 1), (0, 0, 0), None,
+                          ACT_NONE, 0.0, None, 0, choose_tile(tuple(out_dims))))
+        be.gather_gemm_multi(calls)
+        return be.sum_slabs_bias_act(slabs, S, bias, act, slope), None
+    y = be.new_act(N, Cout, *out_dims, like=x1)
     be.gather_gemm(x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), taps, K[1], K[2],
                    wp, Npad, y, out_dims, Cout, (1, 1, 1), (0, 0, 0), bias, act, slope, stats, stats_mode,
                    choose_tile(tuple(out_dims)))

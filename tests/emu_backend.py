@@ -90,8 +90,16 @@ def gather_gemm(x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
 def gather_gemm_multi(calls):
     assert 1 <= len(calls) <= 8
     for a in calls:
-        assert a[0] is calls[0][0] and a[11] is calls[0][11] and a[13] is calls[0][13]  # same x1 / wp / y
+        assert a[0] is calls[0][0] and a[11] is calls[0][11]  # same x1 / wp (y may differ: split-K slabs)
         gather_gemm(*a)
+
+
+def sum_slabs_bias_act(slabs, S, bias, act, slope):
+    SN = slabs.shape[0]
+    v = slabs.reshape(S, SN // S, *slabs.shape[1:]).sum(0)
+    if bias is not None:
+        v = v + bias.view(1, -1, 1, 1, 1)
+    return _act(v, act, slope).contiguous(memory_format=torch.channels_last_3d)
 
 
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):

@@ -198,3 +198,16 @@ def test_phase_taps_cover_every_tap_once():
                 assert o * s - p + k == s * q + ph
                 seen.append(k)
         assert sorted(seen) == list(range(K))
+
+
+def test_split_k_many_depth_taps(emu):
+    """feature_fuse-like: one output depth slice, 16 depth taps -> split-K slabs + combine."""
+    x = _rand(1, 32, 16, 9, 10).requires_grad_()
+    w = _rand(64, 32, 16, 3, 3).requires_grad_()
+    b = _rand(64).requires_grad_()
+    y = ops.fused_conv3d(x, w, b, 1, (0, 1, 1), act=ops.ACT_LRELU, slope=0.2)
+    ref = F.leaky_relu(F.conv3d(x, w, b, 1, (0, 1, 1)), 0.2)
+    _cmp(y, ref)
+    g = torch.randn_like(ref)
+    for a, e in zip(torch.autograd.grad(y, (x, w, b), g), torch.autograd.grad(ref, (x, w, b), g)):
+        _cmp(a, e)

@@ -98,6 +98,15 @@ def test_halo_tile_conv_virtual_concat_instnorm():
          [x1, x2, w, b, ga, be], [True, True, True, False, True, True])
 
 
+def test_split_k_many_depth_taps():
+    """feature_fuse-like contraction (one output slice, 32 depth taps): split-K slabs + combine."""
+    x = _mk(1, 64, 32, 24, 20, seed=60)
+    w = _mk(64, 64, 32, 3, 3, seed=61) / (64 * 32 * 9) ** 0.5
+    b = _mk(64, seed=62)
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, (0, 1, 1), act=ops.ACT_LRELU, slope=0.2),
+         lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, 1, (0, 1, 1)), 0.2), [x, w, b], [True, True, True])
+
+
 TCONVS = [
     (128, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (1, 4, 9, 10)),
     (64, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 3, 5, 6)),
