@@ -92,8 +92,17 @@ typedef struct {
   /* lattice tile: a td x th x tw brick with td*th*tw == 128, or tile_d == 0
    * for runs of 128 consecutive flattened lattice points (odd extents)         */
   int32_t tile_d, tile_h, tile_w;
+  /* optional scratch for the Winograd F(2x2,3x3)-over-(H,W) kernel (NULL = never use
+   * it).  When given, >= rehr_gather_gemm_wino_bytes(d) bytes, 16-byte aligned, and
+   * the contraction is a unit-stride one with taps {-1,0,+1} along H and W, the
+   * library transforms wp into it and runs the 2.25x-fewer-multiplications path
+   * (same fp32 results up to the transform's rounding, ~1e-6 relative).          */
+  float* wino_ws;
+  int64_t wino_ws_bytes;
 } rehr_gather_gemm_desc;
 
+/* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
+int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
 int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);
 /* The stride phases of ONE layer (same x1/x2, wp, y, N, Npad; count <= 8), differing
  * only in lattice, taps and destination offset, in a single grid.                   */

@@ -24,6 +24,7 @@
 //    atomics, one per channel per wave).
 #include "common.h"
 #include "halo_conv.h"
+#include "wino_conv.h"
 
 namespace {
 
@@ -466,6 +467,11 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
   GGMulti pm;
   int n = 0;
   for (int i = 0; i < count; ++i) {
+    if (descs[i].wino_ws != nullptr) {  // fewer multiplications beat better tiling: Winograd first
+      const int wrc = wino_conv_try(descs[i], st);
+      if (wrc == REHR_OK) continue;
+      if (wrc != REHR_ENOSUP) return wrc;
+    }
     if (descs[i].tile_d >= 0) {  // the halo-tile kernel takes what it is good at, one launch each
       const int hrc = halo_conv_try(descs[i], st);
       if (hrc == REHR_OK) continue;
@@ -477,6 +483,11 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
   }
   if (n == 0) return REHR_OK;
   return launch_generic(pm, n, st);
+}
+
+extern "C" int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* dp) {
+  if (dp == nullptr || validate(*dp) != REHR_OK) return 0;
+  return wino_workspace_bytes(*dp);
 }
 
 extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* stream) {

@@ -8,6 +8,7 @@ device memory and streams only; all arithmetic happens in librehrseg_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import functools
 
 import torch
@@ -116,6 +117,10 @@ def pack_weights(w, A, Apad, B, T, transpose):
     return out
 
 
+# Winograd F(2x2,3x3) over (H,W) for unit-stride 3x3 taps (REHR_WINOGRAD=0 switches it off)
+USE_WINOGRAD = os.environ.get("REHR_WINOGRAD", "1") != "0"
+
+
 def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
              os_, ob, bias, act, slope, stats, stats_mode, tile):
     _chk_dev(x1, x2, wp, y, bias, stats)
@@ -139,6 +144,14 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d.bias, d.act, d.slope = _ptr(bias), act, slope
     d.stats, d.stats_mode = _ptr(stats), stats_mode
     d.tile_d, d.tile_h, d.tile_w = tile
+    d.wino_ws, d.wino_ws_bytes = None, 0
+    keep = None
+    if USE_WINOGRAD and tile[0] >= 0:
+        nbytes = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
+        if nbytes > 0:
+            keep = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
+            d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
+    d._keep = keep  # scratch stays referenced until the launch has been enqueued
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
 
 

@@ -44,6 +44,7 @@ class GatherGemmDesc(C.Structure):
         ("bias", _vp), ("act", _i32), ("slope", _f32),
         ("stats", _vp), ("stats_mode", _i32),
         ("tile_d", _i32), ("tile_h", _i32), ("tile_w", _i32),
+        ("wino_ws", _vp), ("wino_ws_bytes", _i64),
     ]
 
 
@@ -77,6 +78,7 @@ _P_GG, _P_WG, _P_DC = C.POINTER(GatherGemmDesc), C.POINTER(WgradDesc), C.POINTER
 
 # name -> (restype, argtypes); must list every function include/rehrseg_hip.h declares
 PROTOTYPES = {
+    "rehr_gather_gemm_wino_bytes": (_i64, [_P_GG]),
     "rehr_gather_gemm_f32": (C.c_int, [_P_GG, _vp]),
     "rehr_gather_gemm_multi_f32": (C.c_int, [_P_GG, _i32, _vp]),
     "rehr_sum_slabs_bias_act_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
