@@ -16,6 +16,7 @@
 //   output  = Y = A^T M A: column combine in registers, row combine across the 4 waves via LDS.
 #include "common.h"
 #include "wino_conv.h"
+#include <cstdlib>
 
 namespace {
 
@@ -73,7 +74,7 @@ __global__ void wino_weights_kernel(const rehr_gather_gemm_desc d, float* __rest
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
   const rehr_gather_gemm_desc& d = p.d;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;  // [PVOX][LDX]; reused as the row-combine exchange buffer at the end
+  float* Xs = smem;  // [2][PVOX][LDX]; reused as the row-combine exchange buffer at the end
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int r = __builtin_amdgcn_readfirstlane(tid >> 6);  // Winograd row of this wave
@@ -86,9 +87,11 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
   const int od = b / p.nb_h;
   const int oh0 = bh_ * 2 * TH, ow0 = bw_ * 2 * TW;
 
-  // B^T rows: V[r] = s1 * d[i1] + s2 * d[i2]
+  // B^T rows: (d0 - d2, d1 + d2, d2 - d1, d1 - d3).  The lane computes R = d[i1] + s2 * d[i2]
+  // (one fma); row 2 comes out negated, which the output transform takes back (rsign).
   const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
-  const float s1 = (r == 2) ? -1.f : 1.f, s2 = (r == 0 || r == 3) ? -1.f : 1.f;
+  const float s2 = (r == 1) ? 1.f : -1.f;
+  const float rsign = (r == 2) ? -1.f : 1.f;
 
   // lane's tile -> patch origin
   const int t_ = col;  // tile index = MFMA row
@@ -132,10 +135,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
       rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NX; ++i)
-      if (pv[i] >= 0) *reinterpret_cast<f32x4*>(Xs + pv[i] * LDX + pq[i] * 4) = rx[i];
+      if (pv[i] >= 0) *reinterpret_cast<f32x4*>(Xs + buf + pv[i] * LDX + pq[i] * 4) = rx[i];
   };
 
   // transformed weights: lane's B fragment of (jd, xi = r*4 + c), k-group kk
@@ -143,65 +146,84 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
   const uint32_t per_b = (uint32_t)d.Npad * d.Cin * 4u;
   const uint32_t ulane = ((uint32_t)(n0 + col) * d.Cin + 4u * half) * 4u;
-  auto load_u = [&](int it, int c, f32x4 (&ub)[4]) {
-    const int jd = it % d.td.count;
-    const int cc = (it / d.td.count) * 32;
-    const uint32_t base = (uint32_t)(jd * 16 + r * 4 + c) * per_b + (uint32_t)cc * 4u + ulane;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      ub[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + kk * 32u, 0, 0));
-  };
-
   f32x16 acc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
 
+  // two LDS slices: item it is read from slice it&1 while item it+1 (fetched one item earlier
+  // into rx) is written to the other one and item it+2 is fetched; one barrier per item.
+  // Inside an item the 4 k-groups are software-pipelined by hand: while k-group kk feeds the
+  // matrix cores, the LDS reads and the weight fragments of kk+1 are in flight.
+  auto read_r = [&](int cur, int kk, f32x4 (&R)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xa + cur + j * LDX + kk * 8);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(xb + cur + j * LDX + kk * 8);
+      R[j] = a + bq * s2;
+    }
+  };
+  auto load_u = [&](int it, int kk, f32x4 (&ub)[4]) {
+    const int jd = it % d.td.count;
+    const int cc = (it / d.td.count) * 32;
+    const uint32_t base = (uint32_t)(jd * 16 + r * 4) * per_b + (uint32_t)(cc + kk * 8) * 4u + ulane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * per_b, 0, 0));
+  };
+  // columns (d0 - d2, d1 + d2, d2 - d1 [negated here, undone at the output], d1 - d3), then 16 MFMAs
+  auto compute = [&](const f32x4 (&R)[4], const f32x4 (&ub)[4]) {
+    f32x4 v[4];
+    v[0] = R[0] - R[2];
+    v[1] = R[1] + R[2];
+    v[2] = R[1] - R[2];
+    v[3] = R[1] - R[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
+  };
+
   fetch(0);
-  stage();
+  stage(0);
+  fetch(1);
+  f32x4 Ra[4], Rb[4], ua[4], ubb[4];
+  load_u(0, 0, ua);
   __syncthreads();
 
-  f32x4 ub0[4], ub1[4];
   for (int it = 0; it < items; ++it) {
-    fetch(it + 1);
-    load_u(it, 0, ub0);
-    // row combine of the lane's 4x4 patch rows: R[j][kk] (j = patch column), all 4 k-groups
-    f32x4 R[4][4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xa + j * LDX + kk * 8);
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(xb + j * LDX + kk * 8);
-        R[j][kk] = a * s1 + bq * s2;
-      }
-    // column combine + MFMAs, one Winograd column at a time, next column's weights in flight
-    auto column = [&](const int c, const f32x4 (&ub)[4]) {
-      const int ja = (c == 0) ? 0 : 1, jb = (c == 3) ? 3 : 2;
-      const float sa = (c == 2) ? -1.f : 1.f, sb = (c == 0 || c == 3) ? -1.f : 1.f;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const f32x4 v = R[ja][kk] * sa + R[jb][kk] * sb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], ub[kk][e], acc[c], 0, 0, 0);
-      }
-    };
-    load_u(it, 1, ub1);
-    column(0, ub0);
-    load_u(it, 2, ub0);
-    column(1, ub1);
-    load_u(it, 3, ub1);
-    column(2, ub0);
-    column(3, ub1);
-    __syncthreads();  // every wave is done with this slice
-    stage();
+    const int cur = (it & 1) * (PVOX * LDX);
+    read_r(cur, 0, Ra);
+    read_r(cur, 1, Rb);
+    load_u(it, 1, ubb);
+    stage(cur ^ (PVOX * LDX));  // item it+1 (zeros past the end)
+    __builtin_amdgcn_sched_barrier(0);
+    compute(Ra, ua);
+    __builtin_amdgcn_sched_barrier(0);
+    read_r(cur, 2, Ra);
+    load_u(it, 2, ua);
+    fetch(it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(Rb, ubb);
+    __builtin_amdgcn_sched_barrier(0);
+    read_r(cur, 3, Rb);
+    load_u(it, 3, ubb);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(Ra, ua);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(it + 1 < items ? it + 1 : it, 0, ua);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(Rb, ubb);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
 
   // ---- output transform.  Columns (registers): T[c'] for c' = 0, 1
-  f32x16 T0 = acc[0] + acc[1] + acc[2];
-  f32x16 T1 = acc[1] - acc[2] - acc[3];
+  // (column 2 and row 2 were accumulated negated)
+  f32x16 T0 = (acc[0] + acc[1] - acc[2]) * rsign;
+  f32x16 T1 = (acc[1] + acc[2] - acc[3]) * rsign;
   // rows across waves through LDS: ex[r][c'][reg][lane]
   float* ex = smem;
 #pragma unroll
@@ -210,25 +232,30 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
     ex[((r * 2 + 1) * 16 + q) * 64 + lane] = T1[q];
   }
   __syncthreads();
-  // wave w -> output position (r' = w >> 1, c' = w & 1) of every tile
+  // wave w -> output position (r' = w >> 1, c' = w & 1) of every tile; branch-free so the LDS
+  // reads go out back to back
   const int ro = r >> 1, co = r & 1;
+  const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
+  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
   const int col_n = n0 + col;
   const bool colok = col_n < d.Cout;
   const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
   float s1_ = 0.f, s2_ = 0.f;
+  float t[4][16];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t[rr][q] = ex[((rr * 2 + co) * 16 + q) * 64 + lane];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const float t0 = ex[((0 * 2 + co) * 16 + q) * 64 + lane], t1 = ex[((1 * 2 + co) * 16 + q) * 64 + lane],
-                t2 = ex[((2 * 2 + co) * 16 + q) * 64 + lane], t3 = ex[((3 * 2 + co) * 16 + q) * 64 + lane];
-    const float yv = ro == 0 ? (t0 + t1 + t2) : (t1 - t2 - t3);
+    const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + k3 * t[3][q] + bv;
+    const float v = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
     const int tile = (q & 3) + 8 * (q >> 2) + 4 * half;  // MFMA C row = tile index
     const int oh = oh0 + 2 * (tile / TW) + ro, ow = ow0 + 2 * (tile % TW) + co;
-    const float v = apply_act(yv + bv, d.act, d.slope);
-    if (colok && oh < d.Lh && ow < d.Lw) {
-      d.y[((((int64_t)n_img * d.Dy + od) * d.Hy + oh) * d.Wy + ow) * d.ldy + col_n] = v;
-      s1_ += v;
-      s2_ += v * v;
-    }
+    const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
+    if (ok) d.y[((((int64_t)n_img * d.Dy + od) * d.Hy + oh) * d.Wy + ow) * d.ldy + col_n] = v;
+    s1_ += ok ? v : 0.f;
+    s2_ += ok ? v * v : 0.f;
   }
   if (d.stats_mode != 0) {
     s1_ += __shfl_xor(s1_, 32, 64);
@@ -241,15 +268,325 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Big-tile variant: 64 Winograd tiles (16 x 16 outputs) x 64 channels per block, ONE block of
+// 4 waves per CU with the full register file (16 accumulator tiles per wave in AGPRs).  Each
+// weight fragment feeds 2 tile groups and each input fragment 2 channel groups, which halves
+// the L2->CU operand traffic per MFMA -- the limiter of the small-tile kernel above (measured:
+// 2.16 ms with, 1.45 ms without operand loads on 512->512 @ 128x16x16).  One wave per SIMD, so
+// all latency hiding is explicit: 4 k-group steps per item, the LDS reads / weight loads of
+// step k+1 in flight under the 64 MFMAs of step k; one barrier per item (256 MFMAs), placed
+// where nothing is pending.
+constexpr int PW2 = 18, PVOX2 = 18 * 18, NX2 = (PVOX2 * 8 + 255) / 256;  // 11 pieces per thread
+constexpr int FMOFF = 8 * PW2 * LDX;  // tile group 1 = tile rows 4..7 = patch rows +8
+
+// U2 in MFMA fragment order: [jd][xi][Npad/32][kchunks][kk][lane 64][4]; lane = half*32 + col
+// holds n = nt*32 + col, ci = chunk*32 + kk*8 + half*4 + e (zero beyond Cin)
+__global__ void wino_weights_frag_kernel(const rehr_gather_gemm_desc d, float* __restrict__ up, int kchunks) {
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  const int cpad = kchunks * 32;
+  const int64_t per = (int64_t)d.Npad * cpad;
+  const int64_t per_src = (int64_t)d.Npad * d.Cin;
+  const int64_t total = (int64_t)d.td.count * per;
+  const int NT = d.Npad / 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int jd = (int)(i / per);
+    const int64_t rem = i - (int64_t)jd * per;
+    const int n = (int)(rem / cpad), ci = (int)(rem - (int64_t)n * cpad);
+    float g[3][3];
+#pragma unroll
+    for (int jh = 0; jh < 3; ++jh)
+#pragma unroll
+      for (int jw = 0; jw < 3; ++jw) {
+        const int a = d.bh + d.th.off0 + d.th.offs * jh + 1;
+        const int b = d.bw + d.tw.off0 + d.tw.offs * jw + 1;
+        const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW + (d.tw.k0 + d.tw.ks * jw);
+        const float v = ci < d.Cin ? d.wp[(int64_t)wt * per_src + (int64_t)n * d.Cin + ci] : 0.f;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb)
+            if (aa == a && bb == b) g[aa][bb] = v;
+      }
+    float t[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) t[r][b] = G[r][0] * g[0][b] + G[r][1] * g[1][b] + G[r][2] * g[2][b];
+    const int nt = n >> 5, col = n & 31, chunk = ci >> 5, kk = (ci >> 3) & 3, half = (ci >> 2) & 1, e = ci & 3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t o = (((((int64_t)jd * 16 + r * 4 + c) * NT + nt) * kchunks + chunk) * 4 + kk) * 256 +
+                          (half * 32 + col) * 4 + e;
+        up[o] = t[r][0] * G[c][0] + t[r][1] * G[c][1] + t[r][2] * G[c][2];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) {
+  const rehr_gather_gemm_desc& d = p.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;  // [2][PVOX2][LDX]; reused as the row-combine exchange buffer at the end
+  constexpr int BUF = PVOX2 * LDX;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int n_img = blockIdx.z;
+  const int nt0 = blockIdx.y * 2, n0 = blockIdx.y * 64;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int bw_ = b % p.nb_w; b /= p.nb_w;
+  const int bh_ = b % p.nb_h;
+  const int od = b / p.nb_h;
+  const int oh0 = bh_ * 16, ow0 = bw_ * 16;
+
+  const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
+  const float s2 = (r == 1) ? 1.f : -1.f;
+  const float rsign = (r == 2) ? -1.f : 1.f;
+  const int th_ = col >> 3, tw_ = col & 7;  // tile of group 0; group 1 = 4 tile rows further
+  const float* xa = Xs + ((2 * th_ + i1) * PW2 + 2 * tw_) * LDX + 4 * half;
+  const float* xb = Xs + ((2 * th_ + i2) * PW2 + 2 * tw_) * LDX + 4 * half;
+
+  // staging pieces of this thread: voxel index in the source slice, validity
+  int pvx[NX2];
+  uint32_t pok = 0;
+#pragma unroll
+  for (int i = 0; i < NX2; ++i) {
+    const int piece = tid + 256 * i;
+    const int v = piece >> 3;
+    const int ph = v / PW2, pw_ = v - ph * PW2;
+    const int ih = oh0 + p.dh0 + ph, iw = ow0 + p.dw0 + pw_;
+    const bool ok = (piece < PVOX2 * 8) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+    pvx[i] = ok ? ih * d.Wi + iw : 0;
+    pok |= (ok ? 1u : 0u) << i;
+  }
+  const int pq = tid & 7;  // 16-byte piece within the voxel's 32 channels (same for all i)
+  const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
+  constexpr int NXA = 6;  // pieces fetched / staged in the first half (the rest in the second)
+  f32x4 rx[NXA];
+  const int items = p.kchunks * d.td.count;
+  auto fetch_to = [&](f32x4 (&rx)[NXA], int it, const int lo, const int hi) {
+    const bool live = it < items;
+    const int ii = live ? it : 0;
+    const int jd = ii % d.td.count;
+    const int cc = (ii / d.td.count) * 32;
+    const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
+    const bool first = cc < d.c1;
+    const float* src = first ? d.x1 : d.x2;
+    const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
+    const int coff = first ? cc : cc - d.c1;
+    const uint32_t nrec = img_elems * ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(src) + (int64_t)n_img * img_elems * ld, 0, nrec, 0x00020000);
+    const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
+    const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
+#pragma unroll
+    for (int i = lo; i < hi; ++i) {
+      const bool ok = dok & ((pok >> i) & 1u);
+      const uint32_t off = base + (uint32_t)pvx[i] * ld * 4u;
+      rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
+    }
+  };
+  auto stage_from = [&](const f32x4 (&rx)[NXA], int buf, const int lo, const int hi) {
+#pragma unroll
+    for (int i = lo; i < hi; ++i) {
+      const int piece = tid + 256 * i;
+      if (piece < PVOX2 * 8) *reinterpret_cast<f32x4*>(Xs + buf + (piece >> 3) * LDX + pq * 4) = rx[i - lo];
+    }
+  };
+  auto fetch = [&](int it, const int lo, const int hi) { fetch_to(rx, it, lo, hi); };
+  auto stage = [&](int buf, const int lo, const int hi) { stage_from(rx, buf, lo, hi); };
+
+  const __amdgpu_buffer_rsrc_t rsu =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
+  const int NT = d.Npad / 32;
+  const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
+  auto load_u = [&](int it, int kk, f32x4 (&ub)[2][4]) {
+    const int jd = it % d.td.count;
+    const int chunk = it / d.td.count;
+    const uint32_t base = (uint32_t)(jd * 16 + r * 4) * xi_stride + (uint32_t)nt0 * nt_stride +
+                          (uint32_t)(chunk * 4 + kk) * 1024u + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        ub[fn][c] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride + fn * nt_stride, 0, 0));
+  };
+
+  f32x16 acc[2][2][4];
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[fm][fn][c][q] = 0.f;
+
+  // A micro-step = (k-group kk, tile group fm) = 32 MFMAs.  While they run, the raw patch rows of
+  // the NEXT micro-step arrive from LDS and are combined (B^T d B, ~24 VALU slotted between the
+  // MFMAs) into its A fragments; weights arrive one k-group (2 micro-steps) ahead.
+  f32x4 ra[4], rb[4];
+  auto issue_reads = [&](int buf, const int kk, const int fm) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * FMOFF + j * LDX + kk * 8);
+      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + fm * FMOFF + j * LDX + kk * 8);
+    }
+  };
+  auto combine = [&](f32x4 (&v)[4]) {
+    f32x4 R[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) R[j] = ra[j] + rb[j] * s2;
+    v[0] = R[0] - R[2];
+    v[1] = R[1] + R[2];
+    v[2] = R[1] - R[2];  // negated column, undone at the output
+    v[3] = R[1] - R[3];
+  };
+  auto mfmas = [&](const int fm, const f32x4 (&v)[4], const f32x4 (&ub)[2][4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[fm][fn][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[fn][c][e], acc[fm][fn][c], 0, 0, 0);
+  };
+// One scheduling region per micro-step: the loads of the next micro-step (ISSUE) are slotted
+// between the first MFMAs, the combine's VALU between the last ones, so the matrix pipe never
+// waits for an issue phase (one wave per SIMD: nobody else would fill the gap).
+#define WINO_MICRO(fm, vcur, vnext, u, ISSUE)                            \
+  __builtin_amdgcn_sched_barrier(0);                                     \
+  ISSUE;                                                                 \
+  mfmas(fm, vcur, u);                                                    \
+  combine(vnext);                                                        \
+  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
+  }                                                                      \
+  _Pragma("unroll") for (int g_ = 0; g_ < 7; ++g_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                   \
+  }                                                                      \
+  _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                   \
+  }                                                                      \
+  _Pragma("unroll") for (int g_ = 0; g_ < 14; ++g_) {                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   \
+  }                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 VA[4], VB[4], u0[2][4], u1[2][4];
+  {  // item 0: all 11 pieces in flight at once (u1's registers are free here)
+    fetch(0, 0, NXA);
+    f32x4 (&rx2)[NXA] = reinterpret_cast<f32x4 (&)[NXA]>(u1);
+    fetch_to(rx2, 0, NXA, NX2);
+    load_u(0, 0, u0);
+    stage(0, 0, NXA);
+    stage_from(rx2, 0, NXA, NX2);
+  }
+  __syncthreads();
+  issue_reads(0, 0, 0);
+  combine(VA);
+
+  for (int it = 0; it < items; ++it) {
+    const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
+    const int itn = it + 1 < items ? it + 1 : it;
+    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 0, 1), load_u(it, 1, u1), fetch(it + 1, 0, NXA)))
+    WINO_MICRO(1, VB, VA, u0, issue_reads(cur, 1, 0))
+    WINO_MICRO(0, VA, VB, u1,
+               (issue_reads(cur, 1, 1), load_u(it, 2, u0), stage(nxt, 0, NXA), fetch(it + 1, NXA, NX2)))
+    WINO_MICRO(1, VB, VA, u1, issue_reads(cur, 2, 0))
+    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 2, 1), load_u(it, 3, u1), stage(nxt, NXA, NX2)))
+    WINO_MICRO(1, VB, VA, u0, issue_reads(cur, 3, 0))
+    WINO_MICRO(0, VA, VB, u1, (issue_reads(cur, 3, 1), load_u(itn, 0, u0)))
+    // every read of slice `cur` has been consumed, every write of `nxt` was issued long ago
+    __syncthreads();
+    WINO_MICRO(1, VB, VA, u1, issue_reads(nxt, 0, 0))
+  }
+#undef WINO_MICRO
+  __syncthreads();
+
+  // ---- output transform: columns in registers, rows across the 4 waves through LDS
+  float* ex = smem;  // [fm*2+fn][r][c'][q][lane]
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) {
+      const f32x16 T0 = (acc[fm][fn][0] + acc[fm][fn][1] - acc[fm][fn][2]) * rsign;
+      const f32x16 T1 = (acc[fm][fn][1] + acc[fm][fn][2] - acc[fm][fn][3]) * rsign;
+      float* e0 = ex + (((fm * 2 + fn) * 4 + r) * 2) * 16 * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        e0[q * 64] = T0[q];
+        e0[(16 + q) * 64] = T1[q];
+      }
+    }
+  __syncthreads();
+  // wave w -> output position (ro, co) of every tile: y = A^T rows (1,1,1,0) / (0,1,-1,-1).
+  // Branch-free (uniform coefficients, activation as max/min) so that the 64 LDS reads of a
+  // channel group are issued back to back instead of one round trip each.
+  const int ro = r >> 1, co = r & 1;
+  const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
+  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn) {
+    const int col_n = n0 + fn * 32 + col;
+    const bool colok = col_n < d.Cout;
+    const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
+    float s1_ = 0.f, s2_ = 0.f;
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+      const float* e0 = ex + ((fm * 2 + fn) * 4 * 2 + co) * 16 * 64 + lane;
+      float t[4][16];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + k3 * t[3][q] + bv;
+        const float v = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
+        const int tile = fm * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        const int oh = oh0 + 2 * (tile >> 3) + ro, ow = ow0 + 2 * (tile & 7) + co;
+        const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
+        if (ok) d.y[((((int64_t)n_img * d.Dy + od) * d.Hy + oh) * d.Wy + ow) * d.ldy + col_n] = v;
+        s1_ += ok ? v : 0.f;
+        s2_ += ok ? v * v : 0.f;
+      }
+    }
+    if (d.stats_mode != 0) {
+      s1_ += __shfl_xor(s1_, 32, 64);
+      s2_ += __shfl_xor(s2_, 32, 64);
+      if (half == 0 && colok) {
+        double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
+        atomicAdd(st, (double)s1_);
+        if (d.stats_mode == 2) atomicAdd(st + 1, (double)s2_);
+      }
+    }
+  }
+}
+
 bool three_taps(const rehr_axis_taps& t, int b) {
   if (t.count != 3) return false;
   const int o0 = b + t.off0, o1 = b + t.off0 + t.offs, o2 = b + t.off0 + 2 * t.offs;
   return (o1 == 0) && ((o0 == -1 && o2 == 1) || (o0 == 1 && o2 == -1));
 }
 
+bool big_ok(const rehr_gather_gemm_desc& d) {
+  if (d.Npad % 64 || d.Lh < 16 || d.Lw < 16) return false;
+  const int64_t nb_h = (d.Lh + 15) / 16, nb_w = (d.Lw + 15) / 16;
+  return nb_h * 16 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13;
+}
+
 }  // namespace
 
-// scratch bytes when the descriptor suits the kernel, else 0
+// scratch bytes when the descriptor suits one of the kernels, else 0
 int64_t wino_workspace_bytes(const rehr_gather_gemm_desc& d) {
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return 0;
   if (d.osd != 1 || d.osh != 1 || d.osw != 1 || d.obd || d.obh || d.obw) return 0;
@@ -257,9 +594,11 @@ int64_t wino_workspace_bytes(const rehr_gather_gemm_desc& d) {
   if (!three_taps(d.th, d.bh) || !three_taps(d.tw, d.bw)) return 0;
   if (d.td.count < 1 || d.td.count > 3) return 0;
   if (d.Lh < 8 || d.Lw < 8) return 0;
+  const bool big = big_ok(d);
   const int64_t nb_h = (d.Lh + 2 * TH - 1) / (2 * TH), nb_w = (d.Lw + 2 * TW - 1) / (2 * TW);
-  if (nb_h * 2 * TH * nb_w * 2 * TW * 10 > (int64_t)d.Lh * d.Lw * 13) return 0;
-  const int64_t need = (int64_t)d.td.count * 16 * d.Npad * d.Cin * (int64_t)sizeof(float);
+  if (!big && nb_h * 2 * TH * nb_w * 2 * TW * 10 > (int64_t)d.Lh * d.Lw * 13) return 0;
+  const int64_t cpad = (int64_t)((d.Cin + 31) / 32) * 32;  // the fragment-order layout pads Cin to 32
+  const int64_t need = (int64_t)d.td.count * 16 * d.Npad * cpad * (int64_t)sizeof(float);
   if (need >= (1ll << 32) - 64) return 0;
   const int64_t img = (int64_t)d.Di * d.Hi * d.Wi * 4;
   if (img * d.ldx1 >= (1ll << 32) - 64 || (d.x2 && img * d.ldx2 >= (1ll << 32) - 64)) return 0;
@@ -272,6 +611,36 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   if (!d.wino_ws) return REHR_ENOSUP;
   const int64_t need = wino_workspace_bytes(d);
   if (need == 0 || d.wino_ws_bytes < need || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;
+  static const bool no_big = getenv("REHR_WINO_SMALL") != nullptr;  // A/B switch for benchmarking
+  WinoParams p;
+  p.d = d;
+  p.kchunks = (d.Cin + 31) / 32;
+  p.dh0 = -1;
+  p.dw0 = -1;
+  p.up = d.wino_ws;
+  p.up_bytes = (uint32_t)need;
+  if (big_ok(d) && !no_big) {
+    const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wino_weights_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws,
+                       p.kchunks);
+    p.nb_h = (d.Lh + 15) / 16;
+    p.nb_w = (d.Lw + 15) / 16;
+    const size_t smem_x = (size_t)2 * PVOX2 * LDX * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
+    const size_t smem = smem_x > smem_e ? smem_x : smem_e;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)wino_conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem) != hipSuccess)
+        return REHR_EHIP;
+      attr_set = true;
+    }
+    dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 64, d.N);
+    hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
+    REHR_LAUNCH_CHECK();
+    return REHR_OK;
+  }
   const int64_t nb_h = (d.Lh + 2 * TH - 1) / (2 * TH), nb_w = (d.Lw + 2 * TW - 1) / (2 * TW);
 
   // weight transform (reads the packed panel, writes the workspace)
@@ -281,16 +650,9 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws);
   }
-  WinoParams p;
-  p.d = d;
   p.nb_h = (int)nb_h;
   p.nb_w = (int)nb_w;
-  p.kchunks = (d.Cin + 31) / 32;
-  p.dh0 = -1;
-  p.dw0 = -1;
-  p.up = d.wino_ws;
-  p.up_bytes = (uint32_t)need;
-  const size_t smem_x = (size_t)PVOX * LDX * sizeof(float), smem_e = (size_t)4 * 2 * 16 * 64 * sizeof(float);
+  const size_t smem_x = (size_t)2 * PVOX * LDX * sizeof(float), smem_e = (size_t)4 * 2 * 16 * 64 * sizeof(float);
   const size_t smem = smem_x > smem_e ? smem_x : smem_e;
   dim3 grid((unsigned)(nb_h * nb_w * d.Ld), d.Npad / 32, d.N);
   hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), smem, stream, p);
