@@ -119,6 +119,7 @@ def pack_weights(w, A, Apad, B, T, transpose):
 
 # Winograd F(2x2,3x3) over (H,W) for unit-stride 3x3 taps (REHR_WINOGRAD=0 switches it off)
 USE_WINOGRAD = os.environ.get("REHR_WINOGRAD", "1") != "0"
+wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
 
 
 def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
@@ -150,6 +151,8 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
         nbytes = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
         if nbytes > 0:
             keep = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
+            global wino_launches
+            wino_launches += 1
             d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0

@@ -78,8 +78,53 @@ HALO = [  # shapes the halo-tile kernel takes (stride 1, Cout <= 64, brick-frien
 ]
 
 
+@pytest.fixture
+def no_winograd(monkeypatch):
+    """The Winograd kernels take unit-stride 3x3 taps first; switch them off to reach the
+    direct kernels behind them."""
+    from rehrseg_amd import hip_backend
+    monkeypatch.setattr(hip_backend, "USE_WINOGRAD", False)
+
+
+WINO = [  # Cin, Cout, K, pad, dims, expected kernel launches through the Winograd path (fwd + dgrad)
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 4, 16, 32)),     # big tile (64 tiles x 64 channels)
+    (48, 64, (3, 3, 3), (1, 1, 1), (2, 3, 32, 16)),     # half last chunk
+    (64, 128, (3, 3, 3), (1, 1, 1), (1, 3, 30, 31)),    # ragged edges: masked tiles
+    (32, 32, (3, 3, 3), (1, 1, 1), (1, 4, 16, 16)),     # 32 channels: small tile kernel
+    (64, 96, (3, 3, 3), (1, 1, 1), (1, 2, 8, 16)),      # Npad 96, 8-row lattice: small tile kernel
+    (32, 64, (1, 3, 3), (0, 1, 1), (2, 3, 16, 16)),     # a single depth tap
+    (128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 16, 16)),    # depth 1: both outer depth taps fall outside
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,pad,dims", WINO)
+def test_winograd_conv(Cin, Cout, K, pad, dims):
+    from rehrseg_amd import hip_backend
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=70)
+    w = _mk(Cout, Cin, *K, seed=71) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=72)
+    before = hip_backend.wino_launches
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, pad, act=ops.ACT_LRELU, slope=0.1),
+         lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, 1, pad), 0.1), [x, w, b], [True, True, True])
+    assert hip_backend.wino_launches - before == 2, "forward and input gradient should both take the Winograd path"
+
+
+def test_winograd_virtual_concat_instnorm():
+    from rehrseg_amd import hip_backend
+    x1, x2 = _mk(2, 32, 3, 16, 16, seed=73), _mk(2, 64, 3, 16, 16, seed=74)
+    w = _mk(64, 96, 3, 3, 3, seed=75) / 51.0
+    b, ga, be = _mk(64, seed=76), _mk(64, seed=77), _mk(64, seed=78)
+    before = hip_backend.wino_launches
+    _run(lambda a, c, w, b, ga, be: ops.fused_conv3d(a, w, b, 1, 1, x2=c, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
+         lambda a, c, w, b, ga, be: F.leaky_relu(
+             F.instance_norm(F.conv3d(torch.cat([a, c], 1), w, b, 1, 1), weight=ga, bias=be), 0.01),
+         [x1, x2, w, b, ga, be], [True, True, True, False, True, True])
+    assert hip_backend.wino_launches > before
+
+
 @pytest.mark.parametrize("Cin,Cout,K,pad,dims", HALO)
-def test_halo_tile_conv(Cin, Cout, K, pad, dims):
+def test_halo_tile_conv(Cin, Cout, K, pad, dims, no_winograd):
     N, D, H, W = dims
     x = _mk(N, Cin, D, H, W, seed=50)
     w = _mk(Cout, Cin, *K, seed=51) / (Cin * K[0] * K[1] * K[2]) ** 0.5
@@ -88,7 +133,7 @@ def test_halo_tile_conv(Cin, Cout, K, pad, dims):
          lambda x, w, b: torch.relu(F.conv3d(x, w, b, 1, pad)), [x, w, b], [True, True, True])
 
 
-def test_halo_tile_conv_virtual_concat_instnorm():
+def test_halo_tile_conv_virtual_concat_instnorm(no_winograd):
     x1, x2 = _mk(2, 32, 4, 16, 16, seed=53), _mk(2, 32, 4, 16, 16, seed=54)
     w = _mk(32, 64, 3, 3, 3, seed=55) / 41.0
     b, ga, be = _mk(32, seed=56), _mk(32, seed=57), _mk(32, seed=58)
