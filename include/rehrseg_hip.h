@@ -148,6 +148,10 @@ typedef struct {
 } rehr_wgrad_desc;
 
 int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* d);
+/* 1 when rehr_wgrad_f32 will take the Winograd path for this descriptor (unit stride,
+ * taps {-1,0,+1} over H and W, >= 64 channels on both sides): the products are formed
+ * in the transform domain, 16 per 2x2 output tile and depth tap instead of 36.       */
+int rehr_wgrad_uses_winograd(const rehr_wgrad_desc* d);
 int rehr_wgrad_f32(const rehr_wgrad_desc* d, void* stream);
 
 /* out[t][a][b] = in[a][b][t] (transpose_ab = 0) or in[b][a][t] (1); rows

@@ -29,3 +29,7 @@ struct BrickPlanOut {
 
 bool wgrad_brick_plan(const rehr_wgrad_desc& d, WGParams& w, BrickPlanOut& out);
 int wgrad_brick_launch(const WGParams& w, const BrickPlanOut& o, hipStream_t stream);
+
+// Winograd weight gradient (wino_wgrad.hip): tried first for unit-stride 3x3 (H, W) taps
+int64_t wino_wgrad_workspace_bytes(const rehr_wgrad_desc& d);  // 0 = not applicable
+int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream);

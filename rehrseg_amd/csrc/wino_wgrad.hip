@@ -1,0 +1,379 @@
+// Winograd weight gradient for unit-stride convolutions with 3x3 taps over (H, W):
+//
+//   dU[jd][xi][co][ci] = sum_{n, od, 2x2 output tiles}  (A dY A^T)[xi][tile][co] * (B^T x B)[xi][tile][ci]
+//   dW[kd][a][b]       = sum_{r,c} G[r][a] G[c][b] dU[jd][(r,c)]            (reduce kernel, fixed order)
+//
+// 16 products per tile and depth tap instead of 36: 2.25x fewer MFMA k-steps than the direct
+// weight gradient, which (fp32 matrix pipe bound, ~105 TF) was the largest item of a step.
+//
+//   block   = 64 co x 64 ci of ONE depth tap, a contiguous range of (sample, depth, 4x16-output
+//             region) items (split-K, slabs reduced deterministically afterwards)
+//   wave r  = Winograd row r: 4 columns x (2 x 2) 32x32 tiles = 16 accumulator tiles in AGPRs
+//             (one wave per SIMD, full register file -- all latency hiding is explicit)
+//   stage   = one region: dY (4 x 16 voxels) and the x patch (6 x 18) in LDS, voxel-major as
+//             they sit in HBM (channels contiguous, rows padded to 68 floats: the two wave halves
+//             land on disjoint bank halves).  The MFMA k index is the TILE, so operands are read
+//             as scalars (ds_read_b32, lane = channel) and transformed in registers.
+//   k-group = 8 tiles (one tile row): 4 quarters (fa, fb) of 16 MFMAs; the operands of the next
+//             k-group are read + transformed one set per quarter, slotted between the MFMAs.
+#include "common.h"
+#include "wgrad_shared.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int RH = 4, RW = 16;           // outputs per staged region = 2 x 8 tiles
+constexpr int XH = RH + 2, XW = RW + 2;  // input patch
+constexpr int YV = RH * RW, XV = XH * XW;
+constexpr int LDC = 68;
+constexpr int YBUF = YV * LDC, XBUF = XV * LDC, BUF = YBUF + XBUF;  // floats per stage
+constexpr int NPY = YV * 16 / 256;                                   // 4 pieces / thread
+constexpr int NPX = (XV * 16 + 255) / 256;                           // 7
+constexpr int NPA = 6;                                               // first half: 4 Y + 2 X pieces
+
+struct WWParams {
+  rehr_wgrad_desc d;
+  int nb_h, nb_w;
+  int items, items_per_split, splits;
+  int a_tiles, c_tiles, Capad, Cgpad;
+  float* slabs;  // [splits][KD][16][Capad][Cgpad]
+};
+
+__global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
+  const rehr_wgrad_desc& d = p.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int split = blockIdx.x;
+  const int at = blockIdx.y / p.c_tiles, ct = blockIdx.y - at * p.c_tiles;
+  const int jd = blockIdx.z;
+  const int ca0 = at * 64, cg0 = ct * 64;
+  const int it0 = split * p.items_per_split;
+  const int it1 = min(it0 + p.items_per_split, p.items);
+  const int nstages = it1 - it0;
+
+  // Z rows (A dY): (y0, y0+y1, y0-y1, -y1) -> ka*y0 + kb*y1, row 3 folded negated
+  const float zka = (r == 3) ? 0.f : 1.f, zkb = (r == 0) ? 0.f : ((r == 2) ? -1.f : 1.f);
+  // V rows (B^T x): (x0-x2, x1+x2, x2-x1 [negated], x1-x3) -> x[i1] + s2 * x[i2]
+  const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
+  const float s2 = (r == 1) ? 1.f : -1.f;
+
+  // ---- staging pieces (16-byte pieces: 16 per voxel; q = tid & 15 for every piece of a thread)
+  const int q = tid & 15;
+  const int64_t l_img = (int64_t)d.Ld * d.Lh * d.Lw * d.ldl, g_img = (int64_t)d.Dg * d.Hg * d.Wg * d.ldg;
+  const uint32_t l_bytes = (uint32_t)(l_img * 4), g_bytes = (uint32_t)(g_img * 4);
+  const bool yq_ok = (ca0 + 4 * q) < d.Ca, xq_ok = (cg0 + 4 * q) < d.Cg;
+  f32x4 rx[NPA];
+  auto fetch = [&](int st, const int lo, const int hi) {  // pieces [lo, hi) of stage st: Y pieces first
+    const bool live = st < nstages;
+    int it = it0 + (live ? st : 0);
+    const int bw_ = it % p.nb_w; it /= p.nb_w;
+    const int bh_ = it % p.nb_h; it /= p.nb_h;
+    const int od = it % d.Ld;
+    const int n = it / d.Ld;
+    const int oh0 = bh_ * RH, ow0 = bw_ * RW;
+    const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.l) + (int64_t)n * l_img, 0, l_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.g) + (int64_t)n * g_img, 0, g_bytes, 0x00020000);
+    const bool dok = live & ((unsigned)id < (unsigned)d.Dg);
+#pragma unroll
+    for (int i = lo; i < hi; ++i) {
+      if (i < NPY) {
+        const int vox = (tid >> 4) + 16 * i;  // 0..63
+        const int gh = oh0 + (vox >> 4), gw = ow0 + (vox & 15);
+        const bool ok = live & yq_ok & (gh < d.Lh) & (gw < d.Lw);
+        const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * q) * 4u;
+        rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : l_bytes, 0, 0));
+      } else {
+        const int vox = (tid >> 4) + 16 * (i - NPY);  // 0..111 (valid < 108)
+        const int row = vox / XW, cw = vox - row * XW;
+        const int ih = oh0 - 1 + row, iw = ow0 - 1 + cw;
+        const bool ok = dok & xq_ok & (vox < XV) & ((unsigned)ih < (unsigned)d.Hg) & ((unsigned)iw < (unsigned)d.Wg);
+        const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * q) * 4u;
+        rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : g_bytes, 0, 0));
+      }
+    }
+  };
+  auto stage = [&](int buf, const int lo, const int hi) {
+#pragma unroll
+    for (int i = lo; i < hi; ++i) {
+      if (i < NPY) {
+        const int vox = (tid >> 4) + 16 * i;
+        *reinterpret_cast<f32x4*>(smem + buf + vox * LDC + 4 * q) = rx[i - lo];
+      } else {
+        const int vox = (tid >> 4) + 16 * (i - NPY);
+        if (vox < XV) *reinterpret_cast<f32x4*>(smem + buf + YBUF + vox * LDC + 4 * q) = rx[i - lo];
+      }
+    }
+  };
+
+  // ---- operand preparation for one k-group (tile row g of the region)
+  // Z[c][e] for 32 co: tiles 4*half + e, dY rows 2g, 2g+1, columns 2*tile + {0,1}
+  const float* ybase = smem + (8 * half) * LDC + col;
+  const float* xbase = smem + YBUF + (8 * half) * LDC + col;
+  auto prep_z = [&](int buf, const int g, const int fa, f32x4 (&Z)[4]) {
+    const float* y0 = ybase + buf + (2 * g) * RW * LDC + fa * 32;
+    const float* y1 = y0 + RW * LDC;
+    float z[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = zka * y0[k * LDC] + zkb * y1[k * LDC];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Z[0][e] = z[2 * e];
+      Z[1][e] = z[2 * e] + z[2 * e + 1];
+      Z[2][e] = z[2 * e] - z[2 * e + 1];
+      Z[3][e] = z[2 * e + 1];  // negated column, undone at the store
+    }
+  };
+  // V[c][e] for 32 ci: patch rows 2g + i1, 2g + i2, columns 8*half .. 8*half + 9
+  auto prep_v = [&](int buf, const int g, const int fb, f32x4 (&V)[4]) {
+    const float* xa = xbase + buf + (2 * g + i1) * XW * LDC + fb * 32;
+    const float* xb = xbase + buf + (2 * g + i2) * XW * LDC + fb * 32;
+    float R[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) R[k] = xa[k * LDC] + s2 * xb[k * LDC];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      V[0][e] = R[2 * e] - R[2 * e + 2];
+      V[1][e] = R[2 * e + 1] + R[2 * e + 2];
+      V[2][e] = R[2 * e + 1] - R[2 * e + 2];  // negated column, undone at the store
+      V[3][e] = R[2 * e + 1] - R[2 * e + 3];
+    }
+  };
+
+  f32x16 acc[2][2][4];
+#pragma unroll
+  for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[fa][fb][c][k] = 0.f;
+  auto mfma16 = [&](const int fa, const int fb, const f32x4 (&Z)[4], const f32x4 (&V)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[fa][fb][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Z[c][e], V[c][e], acc[fa][fb][c], 0, 0, 0);
+  };
+// One scheduling region per quarter: 16 MFMAs with the PREP work slotted in (LDS reads first,
+// then global loads / LDS writes of the staging pipeline, the transforms' VALU last).
+#define WW_QUARTER(fa, fb, ZS, VS, PREP)                                 \
+  __builtin_amdgcn_sched_barrier(0);                                     \
+  PREP;                                                                  \
+  mfma16(fa, fb, ZS[fa], VS[fb]);                                        \
+  _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                   \
+  }                                                                      \
+  _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                   \
+  }                                                                      \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+  __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);                     \
+  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   \
+  }                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 ZP[2][4], VP[2][4], ZQ[2][4], VQ[2][4];
+  if (nstages > 0) {
+    // prologue: stage 0 complete in buffer 0, first half of stage 1 in buffer 1, second half in flight
+    fetch(0, 0, NPA);
+    stage(0, 0, NPA);
+    fetch(0, NPA, NPY + NPX);
+    stage(0, NPA, NPY + NPX);
+    fetch(1, 0, NPA);
+    stage(BUF, 0, NPA);
+    fetch(1, NPA, NPY + NPX);
+    __syncthreads();
+    prep_z(0, 0, 0, ZP[0]);
+    prep_v(0, 0, 0, VP[0]);
+    prep_z(0, 0, 1, ZP[1]);
+    prep_v(0, 0, 1, VP[1]);
+
+    for (int st = 0; st < nstages; ++st) {
+      const int cur = (st & 1) * BUF, nxt = cur ^ BUF;
+      // tile row 0 with set P; set Q <- tile row 1 of this stage.  Staging: second half of stage
+      // st+1 lands in nxt (free since the previous midpoint), first half of st+2 is fetched.
+      WW_QUARTER(0, 0, ZP, VP, (prep_z(cur, 1, 0, ZQ[0]), stage(nxt, NPA, NPY + NPX), fetch(st + 2, 0, NPA)))
+      WW_QUARTER(0, 1, ZP, VP, prep_v(cur, 1, 0, VQ[0]))
+      WW_QUARTER(1, 0, ZP, VP, prep_z(cur, 1, 1, ZQ[1]))
+      WW_QUARTER(1, 1, ZP, VP, prep_v(cur, 1, 1, VQ[1]))
+      // midpoint: nobody reads `cur` any more, stage st+1 is complete in `nxt`
+      __syncthreads();
+      WW_QUARTER(0, 0, ZQ, VQ, (prep_z(nxt, 0, 0, ZP[0]), stage(cur, 0, NPA), fetch(st + 2, NPA, NPY + NPX)))
+      WW_QUARTER(0, 1, ZQ, VQ, prep_v(nxt, 0, 0, VP[0]))
+      WW_QUARTER(1, 0, ZQ, VQ, prep_z(nxt, 0, 1, ZP[1]))
+      WW_QUARTER(1, 1, ZQ, VQ, prep_v(nxt, 0, 1, VP[1]))
+    }
+  }
+#undef WW_QUARTER
+
+  // ---- store the 16 tiles of this wave: slab[split][jd][r*4+c][co][ci], signs of the folded
+  // negations taken back (Z row 3, V row 2, Z column 3, V column 2)
+  const float rs = ((r == 3) ? -1.f : 1.f) * ((r == 2) ? -1.f : 1.f);
+  float* slab = p.slabs + (((int64_t)split * d.td.count + jd) * 16 + r * 4) * (int64_t)p.Capad * p.Cgpad;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float sgn = (c >= 2) ? -rs : rs;
+    float* sc = slab + (int64_t)c * p.Capad * p.Cgpad;
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
+          sc[(int64_t)(ca0 + fa * 32 + row) * p.Cgpad + cg0 + fb * 32 + col] = sgn * acc[fa][fb][c][k];
+        }
+  }
+}
+
+// dst[co*sa + ci*sc + tap*st] (+)= sum_{r,c} G[r][a] G[c][b] sum_splits slab[s][jd][r*4+c][co][ci]
+__global__ void wino_wgrad_reduce_kernel(const WWParams p) {
+  const rehr_wgrad_desc& d = p.d;
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  const int KD = d.td.count;
+  const int64_t total = (int64_t)KD * d.Ca * d.Cg;
+  const int64_t plane = (int64_t)p.Capad * p.Cgpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % d.Cg);
+    const int64_t t = i / d.Cg;
+    const int co = (int)(t % d.Ca);
+    const int jd = (int)(t / d.Ca);
+    float u[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) u[x] = 0.f;
+    for (int s = 0; s < p.splits; ++s) {
+      const float* sp = p.slabs + (((int64_t)s * KD + jd) * 16) * plane + (int64_t)co * p.Cgpad + ci;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) u[x] += sp[x * plane];
+    }
+    float tmp[3][4];  // G^T u : [a][c]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        tmp[a][c] = G[0][a] * u[c] + G[1][a] * u[4 + c] + G[2][a] * u[8 + c] + G[3][a] * u[12 + c];
+#pragma unroll
+    for (int jh = 0; jh < 3; ++jh)
+#pragma unroll
+      for (int jw = 0; jw < 3; ++jw) {
+        const int a = d.bh + d.th.off0 + d.th.offs * jh + 1, b = d.bw + d.tw.off0 + d.tw.offs * jw + 1;
+        float v = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb)
+            if (aa == a && bb == b)
+              v = tmp[aa][0] * G[0][bb] + tmp[aa][1] * G[1][bb] + tmp[aa][2] * G[2][bb] + tmp[aa][3] * G[3][bb];
+        const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW + (d.tw.k0 + d.tw.ks * jw);
+        float* o = d.dst + co * d.dst_sa + ci * d.dst_sc + wt * d.dst_st;
+        *o = d.accumulate ? (*o + v) : v;
+      }
+  }
+}
+
+bool three_taps_w(const rehr_axis_taps& t, int b) {
+  if (t.count != 3) return false;
+  const int o0 = b + t.off0, o1 = b + t.off0 + t.offs, o2 = b + t.off0 + 2 * t.offs;
+  return (o1 == 0) && ((o0 == -1 && o2 == 1) || (o0 == 1 && o2 == -1));
+}
+
+bool plan(const rehr_wgrad_desc& d, WWParams& p) {
+  static const bool off = getenv("REHR_WINO_WGRAD") && getenv("REHR_WINO_WGRAD")[0] == '0';
+  if (off) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
+  if (!three_taps_w(d.th, d.bh) || !three_taps_w(d.tw, d.bw)) return false;
+  if (d.td.count < 1 || d.td.count > 3) return false;
+  if (d.Hg != d.Lh || d.Wg != d.Lw) return false;
+  if (d.Ca < 64 || d.Cg < 64 || d.Ca % 4 || d.Cg % 4) return false;
+  if (d.Lh < 4 || d.Lw < 16) return false;
+  p.d = d;
+  p.nb_h = (d.Lh + RH - 1) / RH;
+  p.nb_w = (d.Lw + RW - 1) / RW;
+  if ((int64_t)p.nb_h * RH * p.nb_w * RW * 10 > (int64_t)d.Lh * d.Lw * 13) return false;
+  const int64_t items = (int64_t)d.N * d.Ld * p.nb_h * p.nb_w;
+  if (items >= (1ll << 30) || items < 4) return false;
+  p.items = (int)items;
+  p.a_tiles = (d.Ca + 63) / 64;
+  p.c_tiles = (d.Cg + 63) / 64;
+  p.Capad = p.a_tiles * 64;
+  p.Cgpad = p.c_tiles * 64;
+  if ((int64_t)p.a_tiles * p.c_tiles > 65535) return false;
+  // channel padding waste (e.g. 96 -> 128) must not eat the gain
+  if ((int64_t)p.Capad * p.Cgpad * 10 > (int64_t)d.Ca * d.Cg * 14) return false;
+  if ((int64_t)d.Ld * d.Lh * d.Lw * d.ldl * 4 >= (1ll << 32) - 64 ||
+      (int64_t)d.Dg * d.Hg * d.Wg * d.ldg * 4 >= (1ll << 32) - 64)
+    return false;
+  // split count: fill whole rounds of 256 single-block CUs, >= 16 stages per block
+  const int tiles = p.a_tiles * p.c_tiles * d.td.count;
+  int best_s = 1;
+  double best_eff = 0.0;
+  for (int k = 1; k <= 4; ++k) {
+    int s = (256 * k) / tiles;
+    if (s < 1) s = 1;
+    if ((int64_t)s * 16 > items) s = (int)(items / 16);
+    if (s < 1) s = 1;
+    const int64_t blocks = (int64_t)s * tiles;
+    const int64_t rounds = (blocks + 255) / 256;
+    const double eff = (double)blocks / (double)(rounds * 256);
+    if (eff > best_eff + 0.03) { best_eff = eff; best_s = s; }
+  }
+  p.splits = best_s;
+  p.items_per_split = (p.items + p.splits - 1) / p.splits;
+  p.splits = (p.items + p.items_per_split - 1) / p.items_per_split;
+  return true;
+}
+
+int64_t slab_floats(const WWParams& p) {
+  return (int64_t)p.splits * p.d.td.count * 16 * p.Capad * p.Cgpad;
+}
+
+}  // namespace
+
+// workspace bytes when the Winograd path takes this descriptor, else 0
+int64_t wino_wgrad_workspace_bytes(const rehr_wgrad_desc& d) {
+  WWParams p;
+  if (!plan(d, p)) return 0;
+  return slab_floats(p) * 4 + (int64_t)d.Ca * 8 + 64;
+}
+
+// REHR_OK launched, REHR_ENOSUP not applicable
+int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
+  WWParams p;
+  if (!plan(d, p)) return REHR_ENOSUP;
+  const int64_t need = slab_floats(p) * 4 + (int64_t)d.Ca * 8 + 64;
+  if (!d.workspace || d.workspace_bytes < need || ((uintptr_t)d.workspace & 15)) return REHR_EINVAL;
+  p.slabs = d.workspace;
+  const size_t smem = (size_t)2 * BUF * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        hipSuccess)
+      return REHR_EHIP;
+    attr_set = true;
+  }
+  dim3 grid(p.splits, p.a_tiles * p.c_tiles, d.td.count);
+  hipLaunchKernelGGL(wino_wgrad_kernel, grid, dim3(256), smem, stream, p);
+  const int64_t total = (int64_t)d.td.count * d.Ca * d.Cg;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  REHR_LAUNCH_CHECK();
+  if (d.dbias) {
+    double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(d.workspace) + ((slab_floats(p) * 4 + 15) / 16) * 16);
+    const int rc = rehr_channel_sum_f32(d.l, d.ldl, (int64_t)d.N * d.Ld * d.Lh * d.Lw, d.Ca, d.dbias, d.accumulate,
+                                        scratch, stream);
+    if (rc != REHR_OK) return rc;
+  }
+  return REHR_OK;
+}

@@ -119,6 +119,7 @@ def pack_weights(w, A, Apad, B, T, transpose):
 
 # Winograd F(2x2,3x3) over (H,W) for unit-stride 3x3 taps (REHR_WINOGRAD=0 switches it off)
 USE_WINOGRAD = os.environ.get("REHR_WINOGRAD", "1") != "0"
+wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
 wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
 
 
@@ -207,6 +208,8 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     nbytes = lib.rehr_wgrad_workspace_bytes(C.byref(d))
     if nbytes < 0:
         L.check(int(nbytes), "rehr_wgrad_workspace_bytes")
+    global wino_wgrad_launches
+    wino_wgrad_launches += int(lib.rehr_wgrad_uses_winograd(C.byref(d)))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
     d.workspace, d.workspace_bytes = _ptr(ws), nbytes
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0

@@ -110,6 +110,29 @@ def test_winograd_conv(Cin, Cout, K, pad, dims):
     assert hip_backend.wino_launches - before == 2, "forward and input gradient should both take the Winograd path"
 
 
+WINO_WGRAD = [  # weight gradients in the transform domain: >= 64 channels both sides, W >= 16
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 4, 16, 32)),
+    (128, 64, (3, 3, 3), (1, 1, 1), (2, 3, 8, 16)),
+    (64, 192, (3, 3, 3), (1, 1, 1), (1, 2, 14, 31)),     # ragged region edges, 3 output-channel tiles
+    (80, 64, (1, 3, 3), (0, 1, 1), (2, 3, 16, 16)),      # channel tail (80 -> 128 padded is refused: direct path)
+    (64, 64, (3, 3, 3), (1, 1, 1), (3, 2, 4, 16)),       # one region per slice, three samples
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,pad,dims", WINO_WGRAD)
+def test_winograd_wgrad(Cin, Cout, K, pad, dims):
+    from rehrseg_amd import hip_backend
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=80)
+    w = _mk(Cout, Cin, *K, seed=81) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=82)
+    before = hip_backend.wino_wgrad_launches
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, pad), lambda x, w, b: F.conv3d(x, w, b, 1, pad),
+         [x, w, b], [True, True, True])
+    expect = 0 if Cin == 80 else 1
+    assert hip_backend.wino_wgrad_launches - before == expect
+
+
 def test_winograd_virtual_concat_instnorm():
     from rehrseg_amd import hip_backend
     x1, x2 = _mk(2, 32, 3, 16, 16, seed=73), _mk(2, 64, 3, 16, 16, seed=74)
