@@ -257,13 +257,22 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
     s1_ += ok ? v : 0.f;
     s2_ += ok ? v * v : 0.f;
   }
-  if (d.stats_mode != 0) {
+  if (d.stats_mode != 0) {  // block-level sums first: one atomic per column and block
     s1_ += __shfl_xor(s1_, 32, 64);
     s2_ += __shfl_xor(s2_, 32, 64);
-    if (half == 0 && colok) {
+    __syncthreads();  // everybody is done reading ex
+    float* red = smem;
+    if (half == 0) {
+      red[(r * 2 + 0) * 32 + col] = s1_;
+      red[(r * 2 + 1) * 32 + col] = s2_;
+    }
+    __syncthreads();
+    if (r == 0 && half == 0 && colok) {
+      const float a1 = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
+      const float a2 = red[32 + col] + red[96 + col] + red[160 + col] + red[224 + col];
       double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
-      atomicAdd(st, (double)s1_);
-      if (d.stats_mode == 2) atomicAdd(st + 1, (double)s2_);
+      atomicAdd(st, (double)a1);
+      if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
     }
   }
 }
@@ -534,6 +543,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   const int ro = r >> 1, co = r & 1;
   const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
   const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
+  float ssum[2][2];
 #pragma unroll
   for (int fn = 0; fn < 2; ++fn) {
     const int col_n = n0 + fn * 32 + col;
@@ -560,13 +570,32 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
         s2_ += ok ? v * v : 0.f;
       }
     }
-    if (d.stats_mode != 0) {
-      s1_ += __shfl_xor(s1_, 32, 64);
-      s2_ += __shfl_xor(s2_, 32, 64);
-      if (half == 0 && colok) {
+    ssum[fn][0] = s1_ + __shfl_xor(s1_, 32, 64);
+    ssum[fn][1] = s2_ + __shfl_xor(s2_, 32, 64);
+  }
+  if (d.stats_mode != 0) {  // block-level sums first: one atomic per column and block
+    __syncthreads();  // everybody is done reading ex
+    float* red = smem;
+    if (half == 0) {
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn) {
+        red[((r * 2 + fn) * 2 + 0) * 32 + col] = ssum[fn][0];
+        red[((r * 2 + fn) * 2 + 1) * 32 + col] = ssum[fn][1];
+      }
+    }
+    __syncthreads();
+    if (r < 2 && half == 0) {  // wave fn sums the four row-waves' partials of its 32 columns
+      const int fn = r, col_n = n0 + fn * 32 + col;
+      if (col_n < d.Cout) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a1 += red[((w * 2 + fn) * 2 + 0) * 32 + col];
+          a2 += red[((w * 2 + fn) * 2 + 1) * 32 + col];
+        }
         double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
-        atomicAdd(st, (double)s1_);
-        if (d.stats_mode == 2) atomicAdd(st + 1, (double)s2_);
+        atomicAdd(st, (double)a1);
+        if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
       }
     }
   }
