@@ -25,21 +25,35 @@ namespace {
 constexpr int RH = 4, RW = 16;           // outputs per staged region = 2 x 8 tiles
 constexpr int XH = RH + 2, XW = RW + 2;  // input patch
 constexpr int YV = RH * RW, XV = XH * XW;
-constexpr int LDC = 68;
-constexpr int YBUF = YV * LDC, XBUF = XV * LDC, BUF = YBUF + XBUF;  // floats per stage
-constexpr int NPY = YV * 16 / 256;                                   // 4 pieces / thread
-constexpr int NPX = (XV * 16 + 255) / 256;                           // 7
-constexpr int NPA = 6;                                               // first half: 4 Y + 2 X pieces
 
 struct WWParams {
   rehr_wgrad_desc d;
   int nb_h, nb_w;
   int items, items_per_split, splits;
   int a_tiles, c_tiles, Capad, Cgpad;
-  float* slabs;  // [splits][KD][16][Capad][Cgpad]
+  int fa, fb;
+  float* slabs;      // [splits][KD][16][Capad][Cgpad]
+  float* slab_bias;  // [splits][Capad] or null: per-split column sums of dY (bias gradient)
 };
 
-__global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
+// FA / FB = 32-channel groups of dY / x per block (2 x 2: one block per CU with the full register
+// file; smaller shapes for 32-channel layers run several blocks per CU).
+template <int FA, int FB>
+struct WWCfg {
+  static constexpr int LDY = FA * 32 + 4, LDX = FB * 32 + 4;  // row pitch: wave halves on disjoint banks
+  static constexpr int YBUF = YV * LDY, XBUF = XV * LDX, BUF = YBUF + XBUF;
+  static constexpr int QY = FA * 8, QX = FB * 8;             // 16-byte pieces per voxel
+  static constexpr int NPY = YV * QY / 256, NPX = (XV * QX + 255) / 256, NP = NPY + NPX;
+  static constexpr int NPA = (NP + 1) / 2;
+  static constexpr int NQ = FA * FB, NPREP = FA + FB;
+  static constexpr int MINB = (FA * FB == 4) ? 1 : ((FA * FB == 2) ? 1 : 2);
+};
+
+template <int FA, int FB>
+__global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(const WWParams p) {
+  using C = WWCfg<FA, FB>;
+  constexpr int LDY = C::LDY, LDX = C::LDX, YBUF = C::YBUF, BUF = C::BUF;
+  constexpr int NPY = C::NPY, NP = C::NP, NPA = C::NPA;
   const rehr_wgrad_desc& d = p.d;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -49,7 +63,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
   const int split = blockIdx.x;
   const int at = blockIdx.y / p.c_tiles, ct = blockIdx.y - at * p.c_tiles;
   const int jd = blockIdx.z;
-  const int ca0 = at * 64, cg0 = ct * 64;
+  const int ca0 = at * (FA * 32), cg0 = ct * (FB * 32);
   const int it0 = split * p.items_per_split;
   const int it1 = min(it0 + p.items_per_split, p.items);
   const int nstages = it1 - it0;
@@ -60,11 +74,13 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
   const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
   const float s2 = (r == 1) ? 1.f : -1.f;
 
-  // ---- staging pieces (16-byte pieces: 16 per voxel; q = tid & 15 for every piece of a thread)
-  const int q = tid & 15;
+  // ---- staging pieces (16-byte pieces, QY / QX per voxel)
+  const int qy = tid & (C::QY - 1), qx = tid & (C::QX - 1);
+  const int vy0 = tid / C::QY, vx0 = tid / C::QX;          // first voxel of this thread
+  constexpr int VYS = 256 / C::QY, VXS = 256 / C::QX;      // voxel step between its pieces
   const int64_t l_img = (int64_t)d.Ld * d.Lh * d.Lw * d.ldl, g_img = (int64_t)d.Dg * d.Hg * d.Wg * d.ldg;
   const uint32_t l_bytes = (uint32_t)(l_img * 4), g_bytes = (uint32_t)(g_img * 4);
-  const bool yq_ok = (ca0 + 4 * q) < d.Ca, xq_ok = (cg0 + 4 * q) < d.Cg;
+  const bool yq_ok = (ca0 + 4 * qy) < d.Ca, xq_ok = (cg0 + 4 * qx) < d.Cg;
   f32x4 rx[NPA];
   auto fetch = [&](int st, const int lo, const int hi) {  // pieces [lo, hi) of stage st: Y pieces first
     const bool live = st < nstages;
@@ -83,17 +99,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
       if (i < NPY) {
-        const int vox = (tid >> 4) + 16 * i;  // 0..63
+        const int vox = vy0 + VYS * i;  // 0..63
         const int gh = oh0 + (vox >> 4), gw = ow0 + (vox & 15);
         const bool ok = live & yq_ok & (gh < d.Lh) & (gw < d.Lw);
-        const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * q) * 4u;
+        const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * qy) * 4u;
         rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : l_bytes, 0, 0));
       } else {
-        const int vox = (tid >> 4) + 16 * (i - NPY);  // 0..111 (valid < 108)
+        const int vox = vx0 + VXS * (i - NPY);  // valid < 108
         const int row = vox / XW, cw = vox - row * XW;
         const int ih = oh0 - 1 + row, iw = ow0 - 1 + cw;
         const bool ok = dok & xq_ok & (vox < XV) & ((unsigned)ih < (unsigned)d.Hg) & ((unsigned)iw < (unsigned)d.Wg);
-        const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * q) * 4u;
+        const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * qx) * 4u;
         rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : g_bytes, 0, 0));
       }
     }
@@ -102,25 +118,28 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
       if (i < NPY) {
-        const int vox = (tid >> 4) + 16 * i;
-        *reinterpret_cast<f32x4*>(smem + buf + vox * LDC + 4 * q) = rx[i - lo];
+        const int vox = vy0 + VYS * i;
+        *reinterpret_cast<f32x4*>(smem + buf + vox * LDY + 4 * qy) = rx[i - lo];
       } else {
-        const int vox = (tid >> 4) + 16 * (i - NPY);
-        if (vox < XV) *reinterpret_cast<f32x4*>(smem + buf + YBUF + vox * LDC + 4 * q) = rx[i - lo];
+        const int vox = vx0 + VXS * (i - NPY);
+        if (vox < XV) *reinterpret_cast<f32x4*>(smem + buf + YBUF + vox * LDX + 4 * qx) = rx[i - lo];
       }
     }
   };
 
+  float bsum[FA];
+#pragma unroll
+  for (int fa = 0; fa < FA; ++fa) bsum[fa] = 0.f;
   // ---- operand preparation for one k-group (tile row g of the region)
   // Z[c][e] for 32 co: tiles 4*half + e, dY rows 2g, 2g+1, columns 2*tile + {0,1}
-  const float* ybase = smem + (8 * half) * LDC + col;
-  const float* xbase = smem + YBUF + (8 * half) * LDC + col;
+  const float* ybase = smem + (8 * half) * LDY + col;
+  const float* xbase = smem + YBUF + (8 * half) * LDX + col;
   auto prep_z = [&](int buf, const int g, const int fa, f32x4 (&Z)[4]) {
-    const float* y0 = ybase + buf + (2 * g) * RW * LDC + fa * 32;
-    const float* y1 = y0 + RW * LDC;
+    const float* y0 = ybase + buf + (2 * g) * RW * LDY + fa * 32;
+    const float* y1 = y0 + RW * LDY;
     float z[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) z[k] = zka * y0[k * LDC] + zkb * y1[k * LDC];
+    for (int k = 0; k < 8; ++k) z[k] = zka * y0[k * LDY] + zkb * y1[k * LDY];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       Z[0][e] = z[2 * e];
@@ -128,14 +147,16 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
       Z[2][e] = z[2 * e] - z[2 * e + 1];
       Z[3][e] = z[2 * e + 1];  // negated column, undone at the store
     }
+    // (row 1, column 1) of A dY A^T is the plain sum of the 2x2 tile: the bias gradient for free
+    bsum[fa] += (Z[1][0] + Z[1][1]) + (Z[1][2] + Z[1][3]);
   };
   // V[c][e] for 32 ci: patch rows 2g + i1, 2g + i2, columns 8*half .. 8*half + 9
   auto prep_v = [&](int buf, const int g, const int fb, f32x4 (&V)[4]) {
-    const float* xa = xbase + buf + (2 * g + i1) * XW * LDC + fb * 32;
-    const float* xb = xbase + buf + (2 * g + i2) * XW * LDC + fb * 32;
+    const float* xa = xbase + buf + (2 * g + i1) * XW * LDX + fb * 32;
+    const float* xb = xbase + buf + (2 * g + i2) * XW * LDX + fb * 32;
     float R[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) R[k] = xa[k * LDC] + s2 * xb[k * LDC];
+    for (int k = 0; k < 10; ++k) R[k] = xa[k * LDX] + s2 * xb[k * LDX];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       V[0][e] = R[2 * e] - R[2 * e + 2];
@@ -144,12 +165,25 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
       V[3][e] = R[2 * e + 1] - R[2 * e + 3];
     }
   };
+  // the FA + FB operand sets of a k-group, interleaved Z0 V0 Z1 V1, spread over its FA*FB quarters
+  auto prep_set = [&](const int j, int buf, const int g, f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4]) {
+    // j-th existing entry of (Z0, V0, Z1, V1)
+    if constexpr (FA == 2 && FB == 2) {
+      if (j & 1) prep_v(buf, g, j >> 1, VS[j >> 1]); else prep_z(buf, g, j >> 1, ZS[j >> 1]);
+    } else if constexpr (FA == 1 && FB == 1) {
+      if (j == 0) prep_z(buf, g, 0, ZS[0]); else prep_v(buf, g, 0, VS[0]);
+    } else if constexpr (FA == 1 && FB == 2) {
+      if (j == 0) prep_z(buf, g, 0, ZS[0]); else prep_v(buf, g, j - 1, VS[j - 1]);
+    } else {
+      if (j == 1) prep_v(buf, g, 0, VS[0]); else prep_z(buf, g, j >> 1, ZS[j >> 1]);
+    }
+  };
 
-  f32x16 acc[2][2][4];
+  f32x16 acc[FA][FB][4];
 #pragma unroll
-  for (int fa = 0; fa < 2; ++fa)
+  for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+    for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -161,63 +195,79 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
       for (int c = 0; c < 4; ++c)
         acc[fa][fb][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Z[c][e], V[c][e], acc[fa][fb][c], 0, 0, 0);
   };
-// One scheduling region per quarter: 16 MFMAs with the PREP work slotted in (LDS reads first,
-// then global loads / LDS writes of the staging pipeline, the transforms' VALU last).
-#define WW_QUARTER(fa, fb, ZS, VS, PREP)                                 \
-  __builtin_amdgcn_sched_barrier(0);                                     \
-  PREP;                                                                  \
-  mfma16(fa, fb, ZS[fa], VS[fb]);                                        \
-  _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                   \
-  }                                                                      \
-  _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                   \
-  }                                                                      \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
-  __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);                     \
-  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   \
-  }                                                                      \
-  __builtin_amdgcn_sched_barrier(0);
+  // One scheduling region per quarter: 16 MFMAs with the preparation of the next k-group's operand
+  // set(s) slotted in (LDS reads first, then global loads / LDS writes of the staging pipeline,
+  // the transforms' VALU last).
+  auto kgroup = [&](f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4], int pbuf, const int pg, f32x4 (&ZN)[FA][4],
+                    f32x4 (&VN)[FB][4], auto&& extra) {
+#pragma unroll
+    for (int qi = 0; qi < C::NQ; ++qi) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < C::NPREP; ++j)
+        if (j * C::NQ / C::NPREP == qi) prep_set(j, pbuf, pg, ZN, VN);
+      if (qi == 0) extra();
+      mfma16(qi / FB, qi % FB, ZS[qi / FB], VS[qi % FB]);
+#pragma unroll
+      for (int g_ = 0; g_ < 5; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, C::NQ == 1 ? 8 : 4, 0);
+      }
+#pragma unroll
+      for (int g_ = 0; g_ < 2; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
+#pragma unroll
+      for (int g_ = 0; g_ < 8; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, C::NQ == 1 ? 8 : 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
-  f32x4 ZP[2][4], VP[2][4], ZQ[2][4], VQ[2][4];
+  f32x4 ZP[FA][4], VP[FB][4], ZQ[FA][4], VQ[FB][4];
   if (nstages > 0) {
     // prologue: stage 0 complete in buffer 0, first half of stage 1 in buffer 1, second half in flight
     fetch(0, 0, NPA);
     stage(0, 0, NPA);
-    fetch(0, NPA, NPY + NPX);
-    stage(0, NPA, NPY + NPX);
+    fetch(0, NPA, NP);
+    stage(0, NPA, NP);
     fetch(1, 0, NPA);
     stage(BUF, 0, NPA);
-    fetch(1, NPA, NPY + NPX);
+    fetch(1, NPA, NP);
     __syncthreads();
-    prep_z(0, 0, 0, ZP[0]);
-    prep_v(0, 0, 0, VP[0]);
-    prep_z(0, 0, 1, ZP[1]);
-    prep_v(0, 0, 1, VP[1]);
+#pragma unroll
+    for (int j = 0; j < C::NPREP; ++j) prep_set(j, 0, 0, ZP, VP);
 
     for (int st = 0; st < nstages; ++st) {
       const int cur = (st & 1) * BUF, nxt = cur ^ BUF;
       // tile row 0 with set P; set Q <- tile row 1 of this stage.  Staging: second half of stage
       // st+1 lands in nxt (free since the previous midpoint), first half of st+2 is fetched.
-      WW_QUARTER(0, 0, ZP, VP, (prep_z(cur, 1, 0, ZQ[0]), stage(nxt, NPA, NPY + NPX), fetch(st + 2, 0, NPA)))
-      WW_QUARTER(0, 1, ZP, VP, prep_v(cur, 1, 0, VQ[0]))
-      WW_QUARTER(1, 0, ZP, VP, prep_z(cur, 1, 1, ZQ[1]))
-      WW_QUARTER(1, 1, ZP, VP, prep_v(cur, 1, 1, VQ[1]))
+      kgroup(ZP, VP, cur, 1, ZQ, VQ, [&]() {
+        stage(nxt, NPA, NP);
+        fetch(st + 2, 0, NPA);
+      });
       // midpoint: nobody reads `cur` any more, stage st+1 is complete in `nxt`
       __syncthreads();
-      WW_QUARTER(0, 0, ZQ, VQ, (prep_z(nxt, 0, 0, ZP[0]), stage(cur, 0, NPA), fetch(st + 2, NPA, NPY + NPX)))
-      WW_QUARTER(0, 1, ZQ, VQ, prep_v(nxt, 0, 0, VP[0]))
-      WW_QUARTER(1, 0, ZQ, VQ, prep_z(nxt, 0, 1, ZP[1]))
-      WW_QUARTER(1, 1, ZQ, VQ, prep_v(nxt, 0, 1, VP[1]))
+      kgroup(ZQ, VQ, nxt, 0, ZP, VP, [&]() {
+        stage(cur, 0, NPA);
+        fetch(st + 2, NPA, NP);
+      });
     }
   }
-#undef WW_QUARTER
 
-  // ---- store the 16 tiles of this wave: slab[split][jd][r*4+c][co][ci], signs of the folded
+  if (p.slab_bias != nullptr && r == 1 && jd == 0 && ct == 0) {
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa) {
+      const float t = bsum[fa] + __shfl_xor(bsum[fa], 32, 64);
+      if (half == 0) p.slab_bias[(int64_t)split * p.Capad + ca0 + fa * 32 + col] = t;
+    }
+  }
+  // ---- store the tiles of this wave: slab[split][jd][r*4+c][co][ci], signs of the folded
   // negations taken back (Z row 3, V row 2, Z column 3, V column 2)
   const float rs = ((r == 3) ? -1.f : 1.f) * ((r == 2) ? -1.f : 1.f);
   float* slab = p.slabs + (((int64_t)split * d.td.count + jd) * 16 + r * 4) * (int64_t)p.Capad * p.Cgpad;
@@ -226,9 +276,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WWParams p) {
     const float sgn = (c >= 2) ? -rs : rs;
     float* sc = slab + (int64_t)c * p.Capad * p.Cgpad;
 #pragma unroll
-    for (int fa = 0; fa < 2; ++fa)
+    for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
-      for (int fb = 0; fb < 2; ++fb)
+      for (int fb = 0; fb < FB; ++fb)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
@@ -280,6 +330,27 @@ __global__ void wino_wgrad_reduce_kernel(const WWParams p) {
         *o = d.accumulate ? (*o + v) : v;
       }
   }
+  if (p.slab_bias != nullptr && d.dbias != nullptr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.Ca; i += (int64_t)gridDim.x * blockDim.x) {
+      float sum = 0.f;
+      for (int k = 0; k < p.splits; ++k) sum += p.slab_bias[(int64_t)k * p.Capad + i];
+      d.dbias[i] = d.accumulate ? (d.dbias[i] + sum) : sum;
+    }
+  }
+}
+
+template <int FA, int FB>
+int launch_ww(const WWParams& p, dim3 grid, hipStream_t stream) {
+  const size_t smem = (size_t)2 * WWCfg<FA, FB>::BUF * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return REHR_EHIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wino_wgrad_kernel<FA, FB>), grid, dim3(256), smem, stream, p);
+  return REHR_OK;
 }
 
 bool three_taps_w(const rehr_axis_taps& t, int b) {
@@ -295,7 +366,7 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   if (!three_taps_w(d.th, d.bh) || !three_taps_w(d.tw, d.bw)) return false;
   if (d.td.count < 1 || d.td.count > 3) return false;
   if (d.Hg != d.Lh || d.Wg != d.Lw) return false;
-  if (d.Ca < 64 || d.Cg < 64 || d.Ca % 4 || d.Cg % 4) return false;
+  if (d.Ca < 32 || d.Cg < 32 || d.Ca % 4 || d.Cg % 4) return false;
   if (d.Lh < 4 || d.Lw < 16) return false;
   p.d = d;
   p.nb_h = (d.Lh + RH - 1) / RH;
@@ -304,10 +375,12 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   const int64_t items = (int64_t)d.N * d.Ld * p.nb_h * p.nb_w;
   if (items >= (1ll << 30) || items < 4) return false;
   p.items = (int)items;
-  p.a_tiles = (d.Ca + 63) / 64;
-  p.c_tiles = (d.Cg + 63) / 64;
-  p.Capad = p.a_tiles * 64;
-  p.Cgpad = p.c_tiles * 64;
+  p.fa = (d.Ca <= 32) ? 1 : 2;  // 32-channel sides take a single 32-wide group
+  p.fb = (d.Cg <= 32) ? 1 : 2;
+  p.a_tiles = (d.Ca + p.fa * 32 - 1) / (p.fa * 32);
+  p.c_tiles = (d.Cg + p.fb * 32 - 1) / (p.fb * 32);
+  p.Capad = p.a_tiles * p.fa * 32;
+  p.Cgpad = p.c_tiles * p.fb * 32;
   if ((int64_t)p.a_tiles * p.c_tiles > 65535) return false;
   // channel padding waste (e.g. 96 -> 128) must not eat the gain
   if ((int64_t)p.Capad * p.Cgpad * 10 > (int64_t)d.Ca * d.Cg * 14) return false;
@@ -316,16 +389,17 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
     return false;
   // split count: fill whole rounds of 256 single-block CUs, >= 16 stages per block
   const int tiles = p.a_tiles * p.c_tiles * d.td.count;
+  const int slots = 256 * ((p.fa * p.fb == 1) ? 2 : 1);  // resident blocks
   int best_s = 1;
   double best_eff = 0.0;
   for (int k = 1; k <= 4; ++k) {
-    int s = (256 * k) / tiles;
+    int s = (slots * k) / tiles;
     if (s < 1) s = 1;
     if ((int64_t)s * 16 > items) s = (int)(items / 16);
     if (s < 1) s = 1;
     const int64_t blocks = (int64_t)s * tiles;
-    const int64_t rounds = (blocks + 255) / 256;
-    const double eff = (double)blocks / (double)(rounds * 256);
+    const int64_t rounds = (blocks + slots - 1) / slots;
+    const double eff = (double)blocks / (double)(rounds * slots);
     if (eff > best_eff + 0.03) { best_eff = eff; best_s = s; }
   }
   p.splits = best_s;
@@ -344,36 +418,28 @@ int64_t slab_floats(const WWParams& p) {
 int64_t wino_wgrad_workspace_bytes(const rehr_wgrad_desc& d) {
   WWParams p;
   if (!plan(d, p)) return 0;
-  return slab_floats(p) * 4 + (int64_t)d.Ca * 8 + 64;
+  return (slab_floats(p) + (int64_t)p.splits * p.Capad) * 4 + 64;
 }
 
 // REHR_OK launched, REHR_ENOSUP not applicable
 int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
   WWParams p;
   if (!plan(d, p)) return REHR_ENOSUP;
-  const int64_t need = slab_floats(p) * 4 + (int64_t)d.Ca * 8 + 64;
+  const int64_t need = (slab_floats(p) + (int64_t)p.splits * p.Capad) * 4 + 64;
   if (!d.workspace || d.workspace_bytes < need || ((uintptr_t)d.workspace & 15)) return REHR_EINVAL;
   p.slabs = d.workspace;
-  const size_t smem = (size_t)2 * BUF * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
-        hipSuccess)
-      return REHR_EHIP;
-    attr_set = true;
-  }
+  p.slab_bias = d.dbias ? d.workspace + slab_floats(p) : nullptr;
   dim3 grid(p.splits, p.a_tiles * p.c_tiles, d.td.count);
-  hipLaunchKernelGGL(wino_wgrad_kernel, grid, dim3(256), smem, stream, p);
+  int rc;
+  if (p.fa == 2 && p.fb == 2) rc = launch_ww<2, 2>(p, grid, stream);
+  else if (p.fa == 1 && p.fb == 1) rc = launch_ww<1, 1>(p, grid, stream);
+  else if (p.fa == 1) rc = launch_ww<1, 2>(p, grid, stream);
+  else rc = launch_ww<2, 1>(p, grid, stream);
+  if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)d.td.count * d.Ca * d.Cg;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
   REHR_LAUNCH_CHECK();
-  if (d.dbias) {
-    double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(d.workspace) + ((slab_floats(p) * 4 + 15) / 16) * 16);
-    const int rc = rehr_channel_sum_f32(d.l, d.ldl, (int64_t)d.N * d.Ld * d.Lh * d.Lw, d.Ca, d.dbias, d.accumulate,
-                                        scratch, stream);
-    if (rc != REHR_OK) return rc;
-  }
   return REHR_OK;
 }

@@ -116,6 +116,9 @@ WINO_WGRAD = [  # weight gradients in the transform domain: >= 64 channels both 
     (64, 192, (3, 3, 3), (1, 1, 1), (1, 2, 14, 31)),     # ragged region edges, 3 output-channel tiles
     (80, 64, (1, 3, 3), (0, 1, 1), (2, 3, 16, 16)),      # channel tail (80 -> 128 padded is refused: direct path)
     (64, 64, (3, 3, 3), (1, 1, 1), (3, 2, 4, 16)),       # one region per slice, three samples
+    (32, 32, (3, 3, 3), (1, 1, 1), (2, 3, 16, 16)),      # 32-channel tiles (1 x 1 groups)
+    (64, 32, (3, 3, 3), (1, 1, 1), (1, 4, 8, 32)),       # 1 x 2 groups
+    (32, 64, (3, 3, 3), (1, 1, 1), (1, 4, 12, 16)),      # 2 x 1 groups
 ]
 
 
