@@ -162,7 +162,7 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
 def gather_gemm(*args):
     d = L.GatherGemmDesc()
     flops = _gg_desc(d, *args)
-    with _timed("gather_gemm", flops):
+    with _timed("wino_conv" if d.wino_ws else "gather_gemm", flops):
         L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
 
 
@@ -209,11 +209,12 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     if nbytes < 0:
         L.check(int(nbytes), "rehr_wgrad_workspace_bytes")
     global wino_wgrad_launches
-    wino_wgrad_launches += int(lib.rehr_wgrad_uses_winograd(C.byref(d)))
+    wino = int(lib.rehr_wgrad_uses_winograd(C.byref(d)))
+    wino_wgrad_launches += wino
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
     d.workspace, d.workspace_bytes = _ptr(ws), nbytes
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
-    with _timed("wgrad", flops):
+    with _timed("wino_wgrad" if wino else "wgrad", flops):
         L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
 
 
