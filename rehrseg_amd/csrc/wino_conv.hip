@@ -30,6 +30,7 @@ struct WinoParams {
   rehr_gather_gemm_desc d;
   int nb_h, nb_w;       // 8 x 16 output regions per depth slice
   int kchunks;
+  int dbg;              // timing experiments only (REHR_WINO_DBG): 1 = no epilogue, 2 = no K loop
   int dh0, dw0;         // source offset of patch row/col 0 relative to the region origin (= -1 here)
   const float* up;      // U[jd][16][Npad][Cin]
   uint32_t up_bytes;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
   constexpr int NXA = 6;  // pieces fetched / staged in the first half (the rest in the second)
   f32x4 rx[NXA];
-  const int items = p.kchunks * d.td.count;
+  const int items = (p.dbg & 2) ? 0 : p.kchunks * d.td.count;
   auto fetch_to = [&](f32x4 (&rx)[NXA], int it, const int lo, const int hi) {
     const bool live = it < items;
     const int ii = live ? it : 0;
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   }
 #undef WINO_MICRO
   __syncthreads();
+  if (p.dbg & 1) return;
 
   // ---- output transform: columns in registers, rows across the 4 waves through LDS
   float* ex = smem;  // [fm*2+fn][r][c'][q][lane]
@@ -544,6 +546,13 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
   const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
   float ssum[2][2];
+  // the lane's first output voxel; every other one is a compile-time multiple of two uniform steps
+  // away (tile row = fm*4 + (q>>2), tile column = (q&3) + 4*half), so interior blocks store with
+  // scalar offsets and no per-element predicate
+  float* ybase = d.y + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
+                 n0 + col;
+  const int64_t rowstep = 2 * (int64_t)d.Wy * d.ldy, colstep = 2 * (int64_t)d.ldy;
+  const bool interior = (oh0 + 16 <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 64 <= d.Cout);
 #pragma unroll
   for (int fn = 0; fn < 2; ++fn) {
     const int col_n = n0 + fn * 32 + col;
@@ -558,16 +567,29 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
+      float v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + k3 * t[3][q] + bv;
-        const float v = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
-        const int tile = fm * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-        const int oh = oh0 + 2 * (tile >> 3) + ro, ow = ow0 + 2 * (tile & 7) + co;
-        const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
-        if (ok) d.y[((((int64_t)n_img * d.Dy + od) * d.Hy + oh) * d.Wy + ow) * d.ldy + col_n] = v;
-        s1_ += ok ? v : 0.f;
-        s2_ += ok ? v * v : 0.f;
+        v[q] = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
+      }
+      float* yb = ybase + fn * 32 + (fm * 4) * rowstep;
+      if (interior) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
+          s1_ += v[q];
+          s2_ += v[q] * v[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
+          const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
+          if (ok) yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
+          s1_ += ok ? v[q] : 0.f;
+          s2_ += ok ? v[q] * v[q] : 0.f;
+        }
       }
     }
     ssum[fn][0] = s1_ + __shfl_xor(s1_, 32, 64);
@@ -648,6 +670,8 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   p.dw0 = -1;
   p.up = d.wino_ws;
   p.up_bytes = (uint32_t)need;
+  static const int dbg = getenv("REHR_WINO_DBG") ? atoi(getenv("REHR_WINO_DBG")) : 0;
+  p.dbg = dbg;
   if (big_ok(d) && !no_big) {
     const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
     int64_t blocks = (total + 255) / 256;
