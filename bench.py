@@ -153,12 +153,13 @@ def main():
         pp = PatchParallel(model)
         opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.99, nesterov=True, weight_decay=3e-5)
         x = torch.randn(2, 1, size, size, size, generator=g).to(dev)
-        lab_lr = torch.randint(0, 2, (2, size, size, size), generator=g).to(dev)
-        lab_hr = torch.randint(0, 2, (2, 4 * size, size, size), generator=g).to(dev)
+        lab_lr = torch.randint(0, 2, (2, 1, size, size, size), generator=g).float().to(dev)
+        lab_hr = torch.randint(0, 2, (2, 1, 4 * size, size, size), generator=g).float().to(dev)
         patches_per_step = 2
         workload = (f"SegModel (nnU-Net 3d_fullres isotropic plan, upscale 4) fwd+bwd+SGD, 2x1x{size}^3 per GPU, "
-                    "CE on LR and HR logits, random-init weights")
-        ce = torch.nn.functional.cross_entropy
+                    "DC+CE (fused HIP loss) on LR and HR logits, random-init weights")
+        from rehrseg_amd.utils.seg_utils import _build_loss
+        ce = _build_loss()   # BASELINE cfg-3: Dice + CE on both heads (utils/seg_utils.py:353-372)
 
         def step():
             pp.zero_grad()

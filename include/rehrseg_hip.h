@@ -272,6 +272,26 @@ int rehr_upsample_depth_bwd_f32(const float* dy, float* dx, int32_t N,
                                 int32_t Di, int32_t Do, int64_t HW, int32_t C,
                                 void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Fused segmentation loss: softmax + cross-entropy, optionally
+ * weighted by the uncertainty map with the reference's (B,D,H,W)*(B,1,D,H,W)
+ * broadcast, + nnU-Net soft Dice, one pass over the logits each way.
+ * Replaces utils/seg_utils.py:289-304 (RobustCrossEntropyLoss), :306-351
+ * (DC_and_weighted_CE_loss) and nnunetv2 MemoryEfficientSoftDiceLoss behind them.
+ *   logits [N][S][ld] (NDHWC, C <= ld, 2 <= C <= 4, N <= 4), target [N][S] float class
+ *   ids, unc NULL or [N][S].  fwd fills stats[N*C*3 + 1] = {I,P,G per (n,c); sum of
+ *   (sum_b ce)*(sum_a unc) or sum of ce}; the caller forms the scalar
+ *     w_ce * stats[last] / (unc ? N*N*S : N*S)
+ *       - w_dice * mean_{n, c >= !do_bg} (2I+smooth)/max(G+P+smooth, 1e-8).
+ *   bwd writes dlogits[N][S][ldd] = *grad_out * d(loss)/d(logits).
+ * ------------------------------------------------------------------------- */
+int rehr_seg_loss_fwd_f32(const float* logits, int32_t ld, const float* target, const float* unc,
+                          int32_t N, int32_t C, int64_t S, double* stats, void* stream);
+int rehr_seg_loss_bwd_f32(const float* logits, int32_t ld, const float* target, const float* unc,
+                          int32_t N, int32_t C, int64_t S, const double* stats, float w_ce,
+                          float w_dice, float smooth, int32_t do_bg, const float* grad_out,
+                          float* dlogits, int32_t ldd, void* stream);
+
 /* Elementwise helpers used by the blocks above. */
 int rehr_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act,
                      float slope, void* stream);

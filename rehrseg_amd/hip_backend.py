@@ -412,3 +412,24 @@ def channel_sum(x):
     L.check(L.load().rehr_channel_sum_f32(_ptr(x), Cc, N * S, Cc, _ptr(out), 0, _ptr(scratch), _stream()),
             "rehr_channel_sum_f32")
     return out
+
+
+def seg_loss_fwd(logits, target, unc):
+    """logits (N,C,D,H,W) NDHWC, target/unc (N,S) float32 -> stats double[N*C*3 + 1]."""
+    _chk_dev(logits, target, unc)
+    N, Cc = logits.shape[0], logits.shape[1]
+    S = logits.shape[2] * logits.shape[3] * logits.shape[4]
+    stats = torch.empty(N * Cc * 3 + 1, dtype=torch.float64, device=logits.device)
+    L.check(L.load().rehr_seg_loss_fwd_f32(_ptr(logits), Cc, _ptr(target), _ptr(unc), N, Cc, S, _ptr(stats),
+                                           _stream()), "rehr_seg_loss_fwd_f32")
+    return stats
+
+
+def seg_loss_bwd(logits, target, unc, stats, w_ce, w_dice, smooth, do_bg, grad_out):
+    _chk_dev(logits, target, unc, stats, grad_out)
+    N, Cc, D, H, W = logits.shape
+    dl = new_act(N, Cc, D, H, W, like=logits)
+    L.check(L.load().rehr_seg_loss_bwd_f32(_ptr(logits), Cc, _ptr(target), _ptr(unc), N, Cc, D * H * W, _ptr(stats),
+                                           float(w_ce), float(w_dice), float(smooth), int(do_bg), _ptr(grad_out),
+                                           _ptr(dl), Cc, _stream()), "rehr_seg_loss_bwd_f32")
+    return dl

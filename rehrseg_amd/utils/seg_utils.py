@@ -88,6 +88,38 @@ def softmax_helper_dim1(x):
     return torch.softmax(x, 1)
 
 
+class _FusedDCCE(torch.autograd.Function):
+    """softmax + (uncertainty-weighted) CE + soft Dice as one HIP pass over the logits each way
+    (include/rehrseg_hip.h: rehr_seg_loss_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, unc, w_ce, w_dice, smooth, do_bg):
+        from .. import hip_backend as hb, ops
+        logits = ops.to_cl(logits)
+        N, C = logits.shape[:2]
+        S = logits.shape[2] * logits.shape[3] * logits.shape[4]
+        target = target.reshape(N, S).to(torch.float32).contiguous()
+        unc = None if unc is None else unc.reshape(N, S).to(torch.float32).contiguous()
+        stats = hb.seg_loss_fwd(logits, target, unc)
+        ipg = stats[:-1].view(N, C, 3)
+        dc = (2 * ipg[..., 0] + smooth) / torch.clip(ipg[..., 2] + ipg[..., 1] + smooth, 1e-8)
+        if not do_bg:
+            dc = dc[:, 1:]
+        loss = w_ce * stats[-1] / (N * N * S if unc is not None else N * S) - w_dice * dc.mean()
+        ctx.save_for_backward(logits, target, unc, stats)
+        ctx.cfg = (w_ce, w_dice, smooth, do_bg)
+        return loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .. import hip_backend as hb
+        logits, target, unc, stats = ctx.saved_tensors
+        w_ce, w_dice, smooth, do_bg = ctx.cfg
+        go = grad_out.to(torch.float32).reshape(1).contiguous()
+        return hb.seg_loss_bwd(logits, target, unc, stats, w_ce, w_dice, smooth, do_bg, go), None, None, None, \
+            None, None, None
+
+
 class DC_and_weighted_CE_loss(nn.Module):
     """ref :306-351: weight_ce * CE(uncertainty-weighted) + weight_dice * soft Dice."""
 
@@ -100,7 +132,18 @@ class DC_and_weighted_CE_loss(nn.Module):
         self.ce = RobustCrossEntropyLoss(**ce_kwargs)
         self.dc = dice_class(apply_nonlin=softmax_helper_dim1, **soft_dice_kwargs)
 
+    def _fusable(self, net_output, target):
+        dc = self.dc
+        return (net_output.is_cuda and net_output.dim() == 5 and self.ignore_label is None and
+                type(dc) is SoftDiceLoss and not dc.batch_dice and dc.apply_nonlin is softmax_helper_dim1 and
+                2 <= net_output.shape[1] <= 4 and net_output.shape[0] <= 4 and
+                target.numel() == net_output.numel() // net_output.shape[1] and
+                self.ce.weight is None and self.ce.label_smoothing == 0.0)
+
     def forward(self, net_output, target, uncertainty=None):
+        if self._fusable(net_output, target):  # device tensors: one HIP pass (no torch composition on the GPU)
+            return _FusedDCCE.apply(net_output, target, uncertainty, float(self.weight_ce), float(self.weight_dice),
+                                    float(self.dc.smooth), bool(self.dc.do_bg))
         if self.ignore_label is not None:
             assert target.shape[1] == 1
             mask = target != self.ignore_label
