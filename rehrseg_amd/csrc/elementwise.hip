@@ -76,21 +76,33 @@ __global__ void se_gate_bwd_w_kernel(const double* __restrict__ dgate, const flo
   }
 }
 // kconst[n][k] = (sum_c W[c][k] * ds[n][c]) / S
-__global__ void se_gate_bwd_k_kernel(const double* __restrict__ dgate, const float* __restrict__ gate,
-                                     const float* __restrict__ w, float* __restrict__ kconst, int N,
-                                     int C, float invS) {
-  const int64_t total = (int64_t)N * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % C), n = (int)(i / C);
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float g = gate[(int64_t)n * C + c];
-      const float ds = (float)dgate[(int64_t)n * C + c] * g * (1.f - g);
-      s += w[(int64_t)c * C + k] * ds;
+// block = 64 columns k x 4 slices of c (a thread per (n,k) walking all C rows serially is one
+// dependent-latency chain per output: 79 us for C = 512)
+__global__ __launch_bounds__(256) void se_gate_bwd_k_kernel(const double* __restrict__ dgate,
+                                                            const float* __restrict__ gate,
+                                                            const float* __restrict__ w, float* __restrict__ kconst,
+                                                            int N, int C, float invS) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.y;
+  const int kl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kl;
+  const int per = (C + 3) / 4, c0 = sl * per, c1 = min(C, c0 + per);
+  float s0 = 0.f, s1 = 0.f;
+  if (k < C) {
+    int c = c0;
+    for (; c + 1 < c1; c += 2) {
+      const float g0 = gate[(int64_t)n * C + c], g1 = gate[(int64_t)n * C + c + 1];
+      s0 += w[(int64_t)c * C + k] * ((float)dgate[(int64_t)n * C + c] * g0 * (1.f - g0));
+      s1 += w[(int64_t)(c + 1) * C + k] * ((float)dgate[(int64_t)n * C + c + 1] * g1 * (1.f - g1));
     }
-    kconst[i] = s * invS;
+    if (c < c1) {
+      const float g0 = gate[(int64_t)n * C + c];
+      s0 += w[(int64_t)c * C + k] * ((float)dgate[(int64_t)n * C + c] * g0 * (1.f - g0));
+    }
   }
+  part[sl][kl] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && k < C) kconst[(int64_t)n * C + k] = (part[0][kl] + part[1][kl] + part[2][kl] + part[3][kl]) * invS;
 }
 
 // ---------------------------------------------------------------- y = act(x*gate + res)
@@ -533,8 +545,8 @@ extern "C" int rehr_se_gate_bwd_f32(const double* dgate_acc, const float* gate, 
     return REHR_EINVAL;
   hipLaunchKernelGGL(se_gate_bwd_w_kernel, dim3(ew_blocks((int64_t)C * C)), dim3(EW_THREADS), 0, ST,
                      dgate_acc, gate, mean, dw, db, N, C);
-  hipLaunchKernelGGL(se_gate_bwd_k_kernel, dim3(ew_blocks((int64_t)N * C)), dim3(EW_THREADS), 0, ST,
-                     dgate_acc, gate, w, kconst, N, C, (float)(1.0 / (double)S));
+  hipLaunchKernelGGL(se_gate_bwd_k_kernel, dim3((C + 63) / 64, N), dim3(256), 0, ST, dgate_acc, gate, w, kconst, N, C,
+                     (float)(1.0 / (double)S));
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

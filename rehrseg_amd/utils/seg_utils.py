@@ -8,6 +8,8 @@ These are HBM-bound reductions over the logits; they run as torch ops on the dev
 `MemoryEfficientSoftDiceLoss` lives in nnunetv2==2.3.1 (absent offline): its published
 formula is restated in `SoftDiceLoss` below -- that term's parity is unpinned.
 """
+import functools
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -202,3 +204,93 @@ class BCEDiceLoss(nn.Module):
 
     def forward(self, input, target):
         return self.alpha * self.bce(input, target) + self.beta * self.dice(input, target)
+
+
+# ----------------------------------------------------------------------------- whole-volume inference
+# (ref utils/seg_utils.py:176-287: nnU-Net style tiled predictor with mirror TTA)
+def compute_steps_for_sliding_window(image_size, tile_size, tile_step_size):
+    """ref :176-199."""
+    assert [i >= j for i, j in zip(image_size, tile_size)], "image size must be as large or larger than patch_size"
+    assert 0 < tile_step_size <= 1, "step_size must be larger than 0 and smaller or equal to 1"
+    target = [i * tile_step_size for i in tile_size]
+    num_steps = [int(np.ceil((i - k) / j)) + 1 for i, j, k in zip(image_size, target, tile_size)]
+    steps = []
+    for dim in range(len(tile_size)):
+        max_step = image_size[dim] - tile_size[dim]
+        actual = max_step / (num_steps[dim] - 1) if num_steps[dim] > 1 else 99999999999
+        steps.append([int(np.round(actual * i)) for i in range(num_steps[dim])])
+    return steps
+
+
+def _internal_get_sliding_window_slicers(image_size, patch_size=[14, 320, 384], tile_step_size=0.5):
+    """ref :229-238."""
+    steps = compute_steps_for_sliding_window(image_size, patch_size, tile_step_size)
+    return [tuple([slice(None), *[slice(si, si + ti) for si, ti in zip((sx, sy, sz), patch_size)]])
+            for sx in steps[0] for sy in steps[1] for sz in steps[2]]
+
+
+def _internal_maybe_mirror_and_predict(model, x, out_idx=None, deep_supervision=True, save=False):
+    """ref :201-227: mean over the identity and the 7 mirrorings of (D,H,W).  The 8 variants are independent
+    (InstanceNorm is per sample), so they go through the network as ONE batch instead of 8 calls; the
+    un-mirrored predictions are summed in the reference's order."""
+    import itertools
+    mirror_axes = (0, 1, 2)
+    assert max(mirror_axes) <= x.ndim - 3, "mirror_axes does not match the dimension of the input!"
+    combos = [c for i in range(len(mirror_axes)) for c in itertools.combinations([m + 2 for m in mirror_axes], i + 1)]
+    B = x.shape[0]
+    pred = model(torch.cat([x] + [torch.flip(x, axes) for axes in combos], 0))
+    if out_idx is not None:
+        pred = pred[out_idx]
+        if out_idx == 0 and deep_supervision:
+            pred = pred[0]
+    prediction = pred[:B].clone()
+    for k, axes in enumerate(combos):
+        prediction += torch.flip(pred[(k + 1) * B:(k + 2) * B], axes)
+    prediction /= (len(combos) + 1)
+    return prediction
+
+
+@functools.lru_cache(maxsize=2)
+def compute_gaussian(tile_size, sigma_scale=1. / 8, value_scaling_factor=1, dtype=torch.float16, device="cpu"):
+    """nnunetv2 compute_gaussian, restated (absent offline -> unpinned): Gaussian importance map of a tile."""
+    from scipy.ndimage import gaussian_filter
+    tmp = np.zeros(tile_size)
+    tmp[tuple(i // 2 for i in tile_size)] = 1
+    g = gaussian_filter(tmp, [i * sigma_scale for i in tile_size], 0, mode="constant", cval=0)
+    g = torch.from_numpy(g)
+    g = g / (torch.max(g) / value_scaling_factor)
+    g = g.to(device=device, dtype=dtype)
+    mask = g == 0
+    g[mask] = torch.min(g[~mask])
+    return g
+
+
+def _internal_predict_sliding_window_return_logits(data, slicers, network, do_on_device=True, out_idx=None,
+                                                   slice_seperation=1, patch_size=[14, 320, 384],
+                                                   use_gaussian=False, deep_supervision=True):
+    """ref :240-287 (fp16 accumulators as there; (sic) `slice_seperation`)."""
+    results_device = data.device if do_on_device else torch.device("cpu")
+    if do_on_device and not data.is_cuda and torch.cuda.is_available():
+        results_device = torch.device("cuda")
+    data = data.to(results_device)
+    predicted_logits = torch.zeros((2, data.shape[1] * slice_seperation, data.shape[2], data.shape[3]),
+                                   dtype=torch.half, device=results_device)
+    n_predictions = torch.zeros((data.shape[1] * slice_seperation, data.shape[2], data.shape[3]), dtype=torch.half,
+                                device=results_device)
+    gaussian = compute_gaussian(tuple(patch_size), sigma_scale=1. / 8, value_scaling_factor=10,
+                                device=str(results_device)) if use_gaussian else 1
+    for i, sl in enumerate(slicers):
+        workon = data[sl][None].to(results_device)
+        prediction = _internal_maybe_mirror_and_predict(network, workon, out_idx, deep_supervision, i == len(slicers) - 1)
+        prediction = prediction[0].to(results_device)
+        msl = tuple([slice(None)] + [slice(sl[k].start * slice_seperation, sl[k].stop * slice_seperation) if k == 1
+                                     else slice(sl[k].start, sl[k].stop) for k in range(1, len(sl))])
+        predicted_logits[msl] += prediction * gaussian
+        n_predictions[msl[1:]] += gaussian
+    predicted_logits /= n_predictions
+    if torch.any(torch.isinf(predicted_logits)):
+        raise RuntimeError("Encountered inf in predicted array. Aborting... If this problem persists, reduce "
+                           "value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32")
+    if use_gaussian:
+        compute_gaussian.cache_clear()
+    return predicted_logits
