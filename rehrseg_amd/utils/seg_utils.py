@@ -3,8 +3,10 @@ path (`utils.seg_utils`): same names, arguments and numerics as utils/seg_utils.
 (zscore_normalization), :289-372 (RobustCrossEntropyLoss, DC_and_weighted_CE_loss,
 _build_loss) and :786-885 (DiceLoss, BCEDiceLoss).
 
-These are HBM-bound reductions over the logits; they run as torch ops on the device for now
-(SURVEY section 8f-1 ranks fusing them into one pass as the next row after the conv path).
+The stage-2 loss (`DC_and_weighted_CE_loss`) runs as one fused HIP pass over the logits each way when
+given device tensors (`_FusedDCCE`); the torch composition below it is the same
+arithmetic and is what the CPU-side tests and the oracle comparisons evaluate.  The tiled predictor
+helpers at the end of the file mirror utils/seg_utils.py:176-287.
 `MemoryEfficientSoftDiceLoss` lives in nnunetv2==2.3.1 (absent offline): its published
 formula is restated in `SoftDiceLoss` below -- that term's parity is unpinned.
 """

@@ -54,4 +54,4 @@ def test_fused_loss_full_size_properties():
     assert torch.isfinite(val)
     assert float(logits.grad.sum(1).abs().max()) <= 1e-9
     val2 = mod((logits.detach() + 7.5), target)
-    assert abs(float(val2) - float(val)) <= 1e-5
+    assert abs(float(val2) - float(val.detach())) <= 1e-5
