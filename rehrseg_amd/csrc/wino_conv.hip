@@ -288,7 +288,14 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
 // step k+1 in flight under the 64 MFMAs of step k; one barrier per item (256 MFMAs), placed
 // where nothing is pending.
 constexpr int PW2 = 18, PVOX2 = 18 * 18, NX2 = (PVOX2 * 8 + 255) / 256;  // 11 pieces per thread
-constexpr int FMOFF = 8 * PW2 * LDX;  // tile group 1 = tile rows 4..7 = patch rows +8
+// LDS patch layout of the big-tile kernel: within a row the 9 even columns come first, then the 9 odd
+// ones, and rows are padded by 8 floats.  A fragment read touches, per 16-lane phase, tiles (th 0..1,
+// tw 0..7) at ONE column parity: neighbouring tiles are then 36 floats (9 bank groups, odd) apart and
+// the two tile rows 32 floats (8 groups) apart -> 16 distinct 4-bank groups.  Voxel-major order had
+// both strides even: SQ_LDS_BANK_CONFLICT was 68 % of SQ_LDS_IDX_ACTIVE.
+constexpr int RP2 = PW2 * LDX + 8;     // row pitch in floats
+constexpr int BUF2 = PW2 * RP2;        // floats per slice buffer
+constexpr int FMOFF = 8 * RP2;         // tile group 1 = tile rows 4..7 = patch rows +8
 
 // U2 in MFMA fragment order: [jd][xi][Npad/32][kchunks][kk][lane 64][4]; lane = half*32 + col
 // holds n = nt*32 + col, ci = chunk*32 + kk*8 + half*4 + e (zero beyond Cin)
@@ -338,8 +345,8 @@ __global__ void wino_weights_frag_kernel(const rehr_gather_gemm_desc d, float* _
 __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) {
   const rehr_gather_gemm_desc& d = p.d;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;  // [2][PVOX2][LDX]; reused as the row-combine exchange buffer at the end
-  constexpr int BUF = PVOX2 * LDX;
+  float* Xs = smem;  // [2][BUF2]; reused as the row-combine exchange buffer at the end
+  constexpr int BUF = BUF2;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -356,17 +363,18 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   const float s2 = (r == 1) ? 1.f : -1.f;
   const float rsign = (r == 2) ? -1.f : 1.f;
   const int th_ = col >> 3, tw_ = col & 7;  // tile of group 0; group 1 = 4 tile rows further
-  const float* xa = Xs + ((2 * th_ + i1) * PW2 + 2 * tw_) * LDX + 4 * half;
-  const float* xb = Xs + ((2 * th_ + i2) * PW2 + 2 * tw_) * LDX + 4 * half;
+  const float* xa = Xs + (2 * th_ + i1) * RP2 + tw_ * LDX + 4 * half;  // column 2*tw_ + j -> slot (j&1)*9 + tw_ + (j>>1)
+  const float* xb = Xs + (2 * th_ + i2) * RP2 + tw_ * LDX + 4 * half;
 
-  // staging pieces of this thread: voxel index in the source slice, validity
+  // staging pieces of this thread (enumerated in LDS order): voxel index in the source slice, validity
   int pvx[NX2];
   uint32_t pok = 0;
 #pragma unroll
   for (int i = 0; i < NX2; ++i) {
     const int piece = tid + 256 * i;
     const int v = piece >> 3;
-    const int ph = v / PW2, pw_ = v - ph * PW2;
+    const int ph = v / PW2, slot = v - ph * PW2;
+    const int pw_ = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
     const int ih = oh0 + p.dh0 + ph, iw = ow0 + p.dw0 + pw_;
     const bool ok = (piece < PVOX2 * 8) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
     pvx[i] = ok ? ih * d.Wi + iw : 0;
@@ -403,7 +411,8 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
       const int piece = tid + 256 * i;
-      if (piece < PVOX2 * 8) *reinterpret_cast<f32x4*>(Xs + buf + (piece >> 3) * LDX + pq * 4) = rx[i - lo];
+      const int v = piece >> 3, row = (v * 3641) >> 16;  // v / 18 for v < 1024
+      if (piece < PVOX2 * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LDX + row * 8 + pq * 4) = rx[i - lo];
     }
   };
   auto fetch = [&](int it, const int lo, const int hi) { fetch_to(rx, it, lo, hi); };
@@ -443,55 +452,53 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   auto issue_reads = [&](int buf, const int kk, const int fm) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * FMOFF + j * LDX + kk * 8);
-      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + fm * FMOFF + j * LDX + kk * 8);
+      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LDX + kk * 8);
+      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LDX + kk * 8);
     }
   };
-  auto combine = [&](f32x4 (&v)[4]) {
-    f32x4 R[4];
+  // two floats per instruction (v_pk_fma_f32 / v_pk_add_f32): the A fragments live as float pairs
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  struct VFrag { f32x2 p[4][2]; };  // [column c][pair]: k-steps e = 2*pair + {0,1}
+  const f32x2 s2v = {s2, s2};
+  auto combine = [&](VFrag& v) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) R[j] = ra[j] + rb[j] * s2;
-    v[0] = R[0] - R[2];
-    v[1] = R[1] + R[2];
-    v[2] = R[1] - R[2];  // negated column, undone at the output
-    v[3] = R[1] - R[3];
+    for (int h = 0; h < 2; ++h) {
+      f32x2 R[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 a = h ? ra[j].hi : ra[j].lo, bq = h ? rb[j].hi : rb[j].lo;
+        R[j] = __builtin_elementwise_fma(bq, s2v, a);
+      }
+      v.p[0][h] = R[0] - R[2];
+      v.p[1][h] = R[1] + R[2];
+      v.p[2][h] = R[1] - R[2];  // negated column, undone at the output
+      v.p[3][h] = R[1] - R[3];
+    }
   };
-  auto mfmas = [&](const int fm, const f32x4 (&v)[4], const f32x4 (&ub)[2][4]) {
+  auto mfmas = [&](const int fm, const VFrag& v, const f32x4 (&ub)[2][4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int fn = 0; fn < 2; ++fn)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          acc[fm][fn][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[fn][c][e], acc[fm][fn][c], 0, 0, 0);
+          acc[fm][fn][c] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(v.p[c][e >> 1][e & 1], ub[fn][c][e], acc[fm][fn][c], 0, 0, 0);
   };
-// One scheduling region per micro-step: the loads of the next micro-step (ISSUE) are slotted
-// between the first MFMAs, the combine's VALU between the last ones, so the matrix pipe never
-// waits for an issue phase (one wave per SIMD: nobody else would fill the gap).
+// One scheduling region per micro-step: the loads of the next micro-step (ISSUE), the 32 MFMAs and
+// the combine's VALU are free to interleave, so the matrix pipe never waits for an issue phase (one
+// wave per SIMD: nobody else would fill the gap).  Explicit sched_group_barrier patterns (1 read per
+// MFMA, bursts, 2 MFMAs per memory instruction) all measured within 2 % of -- and slightly behind --
+// the compiler's own interleaving, so none is imposed.
 #define WINO_MICRO(fm, vcur, vnext, u, ISSUE)                            \
   __builtin_amdgcn_sched_barrier(0);                                     \
   ISSUE;                                                                 \
   mfmas(fm, vcur, u);                                                    \
   combine(vnext);                                                        \
-  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
-  }                                                                      \
-  _Pragma("unroll") for (int g_ = 0; g_ < 7; ++g_) {                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                   \
-  }                                                                      \
-  _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                   \
-  }                                                                      \
-  _Pragma("unroll") for (int g_ = 0; g_ < 14; ++g_) {                    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   \
-  }                                                                      \
   __builtin_amdgcn_sched_barrier(0);
 
-  f32x4 VA[4], VB[4], u0[2][4], u1[2][4];
+  VFrag VA, VB;
+  f32x4 u0[2][4], u1[2][4];
   {  // item 0: all 11 pieces in flight at once (u1's registers are free here)
     fetch(0, 0, NXA);
     f32x4 (&rx2)[NXA] = reinterpret_cast<f32x4 (&)[NXA]>(u1);
@@ -680,7 +687,7 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
                        p.kchunks);
     p.nb_h = (d.Lh + 15) / 16;
     p.nb_w = (d.Lw + 15) / 16;
-    const size_t smem_x = (size_t)2 * PVOX2 * LDX * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
+    const size_t smem_x = (size_t)2 * BUF2 * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
     const size_t smem = smem_x > smem_e ? smem_x : smem_e;
     static bool attr_set = false;
     if (!attr_set) {

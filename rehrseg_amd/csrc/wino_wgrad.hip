@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
       for (int c = 0; c < 4; ++c)
         acc[fa][fb][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Z[c][e], V[c][e], acc[fa][fb][c], 0, 0, 0);
   };
-  // One scheduling region per quarter: 16 MFMAs with the preparation of the next k-group's operand
-  // set(s) slotted in (LDS reads first, then global loads / LDS writes of the staging pipeline,
-  // the transforms' VALU last).
+  // One scheduling region per quarter: 16 MFMAs and the preparation of the next k-group's operand
+  // set(s) (LDS reads, staging traffic, the transforms' VALU) interleave freely inside it; imposing
+  // an explicit sched_group_barrier order measured the same.
   auto kgroup = [&](f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4], int pbuf, const int pg, f32x4 (&ZN)[FA][4],
                     f32x4 (&VN)[FB][4], auto&& extra) {
 #pragma unroll
@@ -208,23 +208,6 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
         if (j * C::NQ / C::NPREP == qi) prep_set(j, pbuf, pg, ZN, VN);
       if (qi == 0) extra();
       mfma16(qi / FB, qi % FB, ZS[qi / FB], VS[qi % FB]);
-#pragma unroll
-      for (int g_ = 0; g_ < 5; ++g_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, C::NQ == 1 ? 8 : 4, 0);
-      }
-#pragma unroll
-      for (int g_ = 0; g_ < 2; ++g_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
-#pragma unroll
-      for (int g_ = 0; g_ < 8; ++g_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, C::NQ == 1 ? 8 : 4, 0);
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
