@@ -94,6 +94,10 @@ WINO = [  # Cin, Cout, K, pad, dims, expected kernel launches through the Winogr
     (64, 96, (3, 3, 3), (1, 1, 1), (1, 2, 8, 16)),      # Npad 96, 8-row lattice: small tile kernel
     (32, 64, (1, 3, 3), (0, 1, 1), (2, 3, 16, 16)),     # a single depth tap
     (128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 16, 16)),    # depth 1: both outer depth taps fall outside
+    (32, 32, (3, 3, 3), (1, 1, 1), (1, 3, 32, 16)),     # wide tile (128 tiles x 32 channels), exact fit
+    (48, 32, (3, 3, 3), (1, 1, 1), (2, 2, 64, 32)),     # wide tile: 3 half chunks, 2 x 2 regions
+    (32, 96, (3, 3, 3), (1, 1, 1), (1, 2, 60, 30)),     # wide tile: 3 channel tiles, ragged edges
+    (64, 32, (1, 3, 3), (0, 1, 1), (1, 2, 32, 48)),     # wide tile, one depth tap
 ]
 
 
