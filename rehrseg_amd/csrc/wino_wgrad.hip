@@ -349,7 +349,7 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   if (!three_taps_w(d.th, d.bh) || !three_taps_w(d.tw, d.bw)) return false;
   if (d.td.count < 1 || d.td.count > 3) return false;
   if (d.Hg != d.Lh || d.Wg != d.Lw) return false;
-  if (d.Ca < 32 || d.Cg < 32 || d.Ca % 4 || d.Cg % 4) return false;
+  if (d.Ca < 16 || d.Cg < 16 || d.Ca % 4 || d.Cg % 4) return false;
   if (d.Lh < 4 || d.Lw < 16) return false;
   p.d = d;
   p.nb_h = (d.Lh + RH - 1) / RH;
@@ -365,8 +365,10 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   p.Capad = p.a_tiles * p.fa * 32;
   p.Cgpad = p.c_tiles * p.fb * 32;
   if ((int64_t)p.a_tiles * p.c_tiles > 65535) return false;
-  // channel padding waste (e.g. 96 -> 128) must not eat the gain
-  if ((int64_t)p.Capad * p.Cgpad * 10 > (int64_t)d.Ca * d.Cg * 14) return false;
+  // channel padding waste (e.g. 96 -> 128) must not eat the gain; a 16-channel side padded to one
+  // 32-wide group still beats the direct kernels by a wide margin (SR head: 8.2 ms -> see DESIGN)
+  const int64_t limit = (p.fa * p.fb == 1) ? 21 : 14;
+  if ((int64_t)p.Capad * p.Cgpad * 10 > (int64_t)d.Ca * d.Cg * limit) return false;
   if ((int64_t)d.Ld * d.Lh * d.Lw * d.ldl * 4 >= (1ll << 32) - 64 ||
       (int64_t)d.Dg * d.Hg * d.Wg * d.ldg * 4 >= (1ll << 32) - 64)
     return false;

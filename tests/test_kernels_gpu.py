@@ -123,6 +123,7 @@ WINO_WGRAD = [  # weight gradients in the transform domain: >= 64 channels both 
     (32, 32, (3, 3, 3), (1, 1, 1), (2, 3, 16, 16)),      # 32-channel tiles (1 x 1 groups)
     (64, 32, (3, 3, 3), (1, 1, 1), (1, 4, 8, 32)),       # 1 x 2 groups
     (32, 64, (3, 3, 3), (1, 1, 1), (1, 4, 12, 16)),      # 2 x 1 groups
+    (32, 16, (3, 3, 3), (1, 1, 1), (2, 4, 16, 32)),      # 16 output channels padded to one 32-wide group (SR head)
 ]
 
 
