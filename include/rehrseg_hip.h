@@ -117,6 +117,14 @@ int rehr_sum_slabs_bias_act_f32(const float* slabs, int32_t S, int64_t slab_stri
                                 const float* bias, float* y, int64_t rows, int32_t C,
                                 int32_t act, float slope, void* stream);
 
+/* The same combine with the statistics epilogue of the gather-GEMM: stats[N][C][2] += {sum, sum of
+ * squares} of the stored value per sample and channel (y is dense [N][SV][C]; stats pre-zeroed by
+ * the caller).  Lets the low-resolution nnU-Net stages (<= 8^3 voxels, 320 channels: 40 tiles on
+ * 256 CUs) run split over their taps.                                                       */
+int rehr_sum_slabs_stats_f32(const float* slabs, int32_t S, int64_t slab_stride, const float* bias,
+                             float* y, int32_t N, int64_t SV, int32_t C, int32_t act, float slope,
+                             double* stats, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Weight gradient (Conv3d.weight.grad / ConvTranspose3d.weight.grad):
  *

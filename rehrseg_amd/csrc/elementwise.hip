@@ -705,6 +705,49 @@ __global__ void sum_slabs_bias_act_kernel(const float* __restrict__ slabs, int S
 }
 }  // namespace
 
+namespace {
+// the same combine for one sample per blockIdx.y, with the per-(n,c) sum / sum of squares of the
+// stored value (SE pool / InstanceNorm statistics of a split-K layer)
+__global__ void sum_slabs_stats_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,
+                                       const float* __restrict__ bias, float* __restrict__ y, int64_t SV, int C,
+                                       int64_t rows_per_block, int act, float slope, double* __restrict__ stats) {
+  const int n = blockIdx.y;
+  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t s_end = s_begin + rows_per_block;
+  if (s_end > SV) s_end = SV;
+  const int64_t base = (int64_t)n * SV;
+  column_reduce<2>(base + s_begin, base + s_end, C, stats + (int64_t)n * C * 2, 2,
+                   [&](int64_t row, int c, double(&acc)[2][4]) {
+                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                     if (bias != nullptr) v = *reinterpret_cast<const f32x4*>(bias + c);
+                     for (int s = 0; s < S; ++s)
+                       v += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + row * C + c);
+#pragma unroll
+                     for (int e = 0; e < 4; ++e) {
+                       v[e] = apply_act(v[e], act, slope);
+                       acc[0][e] += v[e];
+                       acc[1][e] += (double)v[e] * v[e];
+                     }
+                     *reinterpret_cast<f32x4*>(y + row * C + c) = v;
+                   });
+}
+}  // namespace
+
+extern "C" int rehr_sum_slabs_stats_f32(const float* slabs, int32_t S, int64_t slab_stride, const float* bias,
+                                        float* y, int32_t N, int64_t SV, int32_t C, int32_t act, float slope,
+                                        double* stats, void* stream) {
+  if (!slabs || !y || !stats || S < 1 || N < 1 || N > 65535 || SV < 1 || C < 4 || C % 4 || C > 1024 ||
+      slab_stride < (int64_t)N * SV * C || slab_stride % 4)
+    return REHR_EINVAL;
+  if ((((uintptr_t)slabs) | ((uintptr_t)y)) & 15) return REHR_EINVAL;
+  const int64_t rpb = rows_per_block_for(SV, C, N);
+  const int blocks = (int)((SV + rpb - 1) / rpb);
+  hipLaunchKernelGGL(sum_slabs_stats_kernel, dim3(blocks, N), dim3(EW_THREADS), 0, (hipStream_t)stream, slabs, S,
+                     slab_stride, bias, y, SV, C, rpb, act, slope, stats);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
 extern "C" int rehr_sum_slabs_bias_act_f32(const float* slabs, int32_t S, int64_t slab_stride, const float* bias,
                                            float* y, int64_t rows, int32_t C, int32_t act, float slope,
                                            void* stream) {

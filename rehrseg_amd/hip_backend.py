@@ -176,13 +176,18 @@ def gather_gemm_multi(calls):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 
 
-def sum_slabs_bias_act(slabs, S, bias, act, slope):
-    """slabs: (S*N, C, D, H, W) NDHWC partial results -> (N, C, D, H, W) = act(bias + sum over S)."""
-    _chk_dev(slabs, bias)
+def sum_slabs_bias_act(slabs, S, bias, act, slope, stats=None):
+    """slabs: (S*N, C, D, H, W) NDHWC partial results -> (N, C, D, H, W) = act(bias + sum over S);
+    `stats` (N, C, 2) double, pre-zeroed: also accumulate the per-(n,c) sum / sum of squares."""
+    _chk_dev(slabs, bias, stats)
     SN, Cc, D, H, W = slabs.shape
     N = SN // S
     y = new_act(N, Cc, D, H, W, like=slabs)
     rows = N * D * H * W
+    if stats is not None:
+        L.check(L.load().rehr_sum_slabs_stats_f32(_ptr(slabs), S, rows * Cc, _ptr(bias), _ptr(y), N, D * H * W, Cc, act,
+                                                  slope, _ptr(stats), _stream()), "rehr_sum_slabs_stats_f32")
+        return y
     L.check(L.load().rehr_sum_slabs_bias_act_f32(_ptr(slabs), S, rows * Cc, _ptr(bias), _ptr(y), rows, Cc, act, slope,
                                                  _stream()), "rehr_sum_slabs_bias_act_f32")
     return y

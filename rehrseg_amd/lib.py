@@ -82,6 +82,7 @@ PROTOTYPES = {
     "rehr_gather_gemm_f32": (C.c_int, [_P_GG, _vp]),
     "rehr_gather_gemm_multi_f32": (C.c_int, [_P_GG, _i32, _vp]),
     "rehr_sum_slabs_bias_act_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "rehr_sum_slabs_stats_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp]),
     "rehr_wgrad_workspace_bytes": (_i64, [_P_WG]),
     "rehr_wgrad_uses_winograd": (C.c_int, [_P_WG]),
     "rehr_wgrad_f32": (C.c_int, [_P_WG, _vp]),

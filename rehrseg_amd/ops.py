@@ -183,6 +183,38 @@ def _thin_out(w, cfg: ConvCfg, has_x2):
             cfg.stride == (1, 1, 1) and w.shape[4] <= 7)
 
 
+def _sub_taps(t, a, b):
+    """taps [a, b) of one axis' arithmetic tap description."""
+    cnt, off0, offs, k0, ks = t
+    return (b - a, off0 + offs * a, offs, k0 + ks * a, ks)
+
+
+def _tap_split(lattice, N, Npad, taps, Cin):
+    """Tap ranges (<= 8) for a split-K launch, or None when the plain launch already fills the chip.
+    Depth taps are split first (single taps or ranges), then the row taps in two."""
+    vox = lattice[0] * lattice[1] * lattice[2]
+    blocks = -(-vox // 128) * (Npad // (128 if Npad % 128 == 0 else (64 if Npad % 64 == 0 else 32))) * N
+    T = taps[0][0] * taps[1][0] * taps[2][0]
+    if blocks > 160 or T * Cin < 2048 or taps[0][0] * taps[1][0] < 2:
+        return None
+    if taps[0][0] <= 3 and taps[1][0] == 3 and taps[2][0] == 3 and taps[1][2] in (1, -1) and taps[2][2] in (1, -1):
+        # unit-stride 3x3 taps: leave lattices the Winograd kernels accept (8x16-output regions, <= 1.3x
+        # padding; librehrseg's wino_workspace_bytes applies the same rule) to them
+        Lh, Lw = lattice[1], lattice[2]
+        if Lh >= 8 and Lw >= 8 and (-(-Lh // 8) * 8) * (-(-Lw // 16) * 16) * 10 <= Lh * Lw * 13:
+            return None
+    want = min(8, max(2, 512 // blocks))
+    kd, kh = taps[0][0], taps[1][0]
+    nd = min(kd, want)
+    nh = 2 if (kh >= 2 and nd * 2 <= want) else 1
+    dstep, hstep = -(-kd // nd), -(-kh // nh)
+    parts = []
+    for a in range(0, kd, dstep):
+        for c in range(0, kh, hstep):
+            parts.append([_sub_taps(taps[0], a, min(kd, a + dstep)), _sub_taps(taps[1], c, min(kh, c + hstep)), taps[2]])
+    return parts if len(parts) > 1 else None
+
+
 def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     """Returns (y, stats).  x2 = second half of a virtual channel concat."""
     be = get_backend()
@@ -219,22 +251,18 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
         return y, stats
     wp, Npad = _pack(w, 0)
     taps = [full_taps(k) for k in K]
-    # Few lattice tiles but a very long K (feature_fuse: 128 tiles x 1152 taps): split the depth
-    # taps over S partial launches in one grid and combine the slabs in a fixed order.
-    ovox = out_dims[0] * out_dims[1] * out_dims[2]
-    blocks = -(-ovox // 128) * (Npad // (128 if Npad % 128 == 0 else (64 if Npad % 64 == 0 else 32))) * N
-    if blocks < 256 and K[0] >= 16 and stats_mode == 0 and Cout % 4 == 0:
-        S = min(8, max(2, 512 // blocks))
+    # Few lattice tiles but a long K (feature_fuse: 128 tiles x 1152 taps; nnU-Net stages at <= 8^3 voxels:
+    # 40 tiles x 27 taps x 320 channels): split the taps over S partial launches in one grid and combine the
+    # slabs in a fixed order (the combine carries bias, activation and the statistics epilogue).
+    parts = _tap_split(out_dims, N, Npad, taps, Cin) if cfg.stride == (1, 1, 1) or K[0] >= 8 else None
+    if parts is not None and Cout % 4 == 0:
+        S = len(parts)
         slabs = be.new_act(S * N, Cout, *out_dims, like=x1)
-        calls, step = [], -(-K[0] // S)
-        for s_i in range(S):
-            a, b_ = s_i * step, min(K[0], (s_i + 1) * step)
-            tp = [(b_ - a, a, 1, a, 1), taps[1], taps[2]]
-            calls.append((x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), tp, K[1], K[2],
-                          wp, Npad, slabs[s_i * N:(s_i + 1) * N], out_dims, Cout, (1, 1, 1), (0, 0, 0), None,
-                          ACT_NONE, 0.0, None, 0, choose_tile(tuple(out_dims))))
+        calls = [(x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), tp, K[1], K[2],
+                  wp, Npad, slabs[s_i * N:(s_i + 1) * N], out_dims, Cout, (1, 1, 1), (0, 0, 0), None,
+                  ACT_NONE, 0.0, None, 0, choose_tile(tuple(out_dims))) for s_i, tp in enumerate(parts)]
         be.gather_gemm_multi(calls)
-        return be.sum_slabs_bias_act(slabs, S, bias, act, slope), None
+        return be.sum_slabs_bias_act(slabs, S, bias, act, slope, stats if stats_mode else None), stats
     y = be.new_act(N, Cout, *out_dims, like=x1)
     be.gather_gemm(x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), taps, K[1], K[2],
                    wp, Npad, y, out_dims, Cout, (1, 1, 1), (0, 0, 0), bias, act, slope, stats, stats_mode,
@@ -267,6 +295,19 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
         else:
             wpart = w if (lo == 0 and cnt == w.shape[1]) else w[:, lo:lo + cnt].contiguous()
             wp, Npad = _pack(wpart, 1)
+            if cfg.stride == (1, 1, 1) and cnt % 4 == 0:
+                # low-resolution stages: split the taps like the forward does (one phase, no epilogue)
+                taps = [phase_taps(K[a], 1, cfg.pad[a], 0) for a in range(3)]
+                parts = _tap_split(in_dims, N, Npad, taps, Cz) if all(t is not None for t in taps) else None
+                if parts is not None:
+                    S = len(parts)
+                    slabs = be.new_act(S * N, cnt, *in_dims, like=dz)
+                    be.gather_gemm_multi([(dz, None, Cz, _spatial(dz), Cz, tuple(in_dims), (1, 1, 1), (0, 0, 0), tp, K[1],
+                                           K[2], wp, Npad, slabs[s_i * N:(s_i + 1) * N], tuple(in_dims), cnt, (1, 1, 1),
+                                           (0, 0, 0), None, ACT_NONE, 0.0, None, 0, choose_tile(tuple(in_dims)))
+                                          for s_i, tp in enumerate(parts)])
+                    out.append(be.sum_slabs_bias_act(slabs, S, None, ACT_NONE, 0.0))
+                    continue
             dx = be.new_act(N, cnt, *in_dims, like=dz, zero=_has_empty_phase(K, cfg.stride, cfg.pad))
             _phased_gather(dz, None, Cz, Cz, wp, Npad, dx, cnt, K, cfg.stride, cfg.pad, None, ACT_NONE, 0.0, None, 0)
         out.append(dx)

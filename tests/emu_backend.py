@@ -94,12 +94,16 @@ def gather_gemm_multi(calls):
         gather_gemm(*a)
 
 
-def sum_slabs_bias_act(slabs, S, bias, act, slope):
+def sum_slabs_bias_act(slabs, S, bias, act, slope, stats=None):
     SN = slabs.shape[0]
     v = slabs.reshape(S, SN // S, *slabs.shape[1:]).sum(0)
     if bias is not None:
         v = v + bias.view(1, -1, 1, 1, 1)
-    return _act(v, act, slope).contiguous(memory_format=torch.channels_last_3d)
+    v = _act(v, act, slope).contiguous(memory_format=torch.channels_last_3d)
+    if stats is not None:
+        stats[..., 0] += v.double().sum((2, 3, 4))
+        stats[..., 1] += (v.double() ** 2).sum((2, 3, 4))
+    return v
 
 
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):

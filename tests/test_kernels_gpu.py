@@ -183,6 +183,17 @@ def test_split_k_many_depth_taps():
          lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, 1, (0, 1, 1)), 0.2), [x, w, b], [True, True, True])
 
 
+def test_split_k_low_resolution_stage_with_instnorm():
+    """nnU-Net bottom stages (<= 8^3 voxels, hundreds of channels): 6 tap ranges in one grid, the combine
+    carries bias + InstanceNorm statistics; the input gradient takes the same route."""
+    x = _mk(2, 128, 4, 8, 8, seed=63)
+    w = _mk(192, 128, 3, 3, 3, seed=64) / (128 * 27) ** 0.5
+    b, ga, be = _mk(192, seed=65), _mk(192, seed=66), _mk(192, seed=67)
+    _run(lambda x, w, b, ga, be: ops.fused_conv3d(x, w, b, 1, 1, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
+         lambda x, w, b, ga, be: F.leaky_relu(F.instance_norm(F.conv3d(x, w, b, 1, 1), weight=ga, bias=be), 0.01),
+         [x, w, b, ga, be], [True, True, False, True, True])
+
+
 TCONVS = [
     (128, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (1, 4, 9, 10)),
     (64, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 3, 5, 6)),
