@@ -468,7 +468,8 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
   int n = 0;
   for (int i = 0; i < count; ++i) {
     if (descs[i].wino_ws != nullptr) {  // fewer multiplications beat better tiling: Winograd first
-      const int wrc = wino_conv_try(descs[i], st);
+      int wrc = wino_conv_try(descs[i], st);
+      if (wrc == REHR_ENOSUP) wrc = wino22_conv_try(descs[i], st);
       if (wrc == REHR_OK) continue;
       if (wrc != REHR_ENOSUP) return wrc;
     }
@@ -487,7 +488,8 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
 
 extern "C" int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* dp) {
   if (dp == nullptr || validate(*dp) != REHR_OK) return 0;
-  return wino_workspace_bytes(*dp);
+  const int64_t b = wino_workspace_bytes(*dp);
+  return b > 0 ? b : wino22_workspace_bytes(*dp);
 }
 
 extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* stream) {

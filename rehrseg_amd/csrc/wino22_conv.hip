@@ -1,0 +1,433 @@
+// Winograd F(2x2, 2x2) over (H, W) for the (., 4, 4) / (., 2, 2) transposed convolutions of the FLAVR
+// decoder (models/FLAVR/FLAVR_arch.py:40-70) -- 27 % of a cfg-2 step ran them as direct GEMMs.
+//
+// A stride-2 transposed convolution with a 4-wide kernel is, per output parity (ph, pw), a unit-stride
+// convolution with 2 x 2 taps on the input lattice; its input gradient is the sum over the 4 source
+// parities of 2 x 2-tap convolutions over the parity sub-lattices of dY.  Both are 2-tap problems:
+//
+//   m0 = (d0 - d1) g0,  m1 = d1 (g0 + g1),  m2 = (d2 - d1) g1;   y0 = m0 + m1,  y1 = m1 + m2
+//
+// i.e. B^T = [[1,-1,0],[0,1,0],[0,-1,1]], G = [[1,0],[1,1],[0,1]], A^T = [[1,1,0],[0,1,1]] (all +-1): 9 products
+// per 2 x 2 outputs instead of 16, exact-fp32 MFMA as everywhere else.
+//
+//   block    = 64 tiles (16 x 16 lattice outputs of one depth slice) x 64 channels, 3 waves: wave r =
+//              Winograd row r with 3 columns x 2 tile groups x 2 channel groups = 12 accumulator tiles
+//   K item   = (source phase, 32-channel chunk, depth tap): the 17 x 17 patch of that phase's sub-lattice
+//              in LDS (double-buffered, even/odd column split + row pad: conflict-free fragment reads)
+//   schedule = as wino_conv_big_kernel: micro-steps (k-group, tile group) of 24 MFMAs, next fragments read
+//              and combined underneath, weights one k-group ahead, one barrier per item
+#include "common.h"
+#include "wino_conv.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int LD = 36;                 // floats per voxel slot (32 channels + 4)
+constexpr int PW = 17;                 // patch is 17 x 17
+constexpr int RP = PW * LD + 12;       // row pitch: two rows = 32 floats mod 64
+constexpr int BUF = PW * RP;           // floats per slice buffer
+constexpr int PVOX = PW * PW;          // 289
+constexpr int NT_ = 192;               // threads
+constexpr int NX = (PVOX * 8 + NT_ - 1) / NT_;  // 13 pieces per thread
+constexpr int NXA = 7;
+constexpr int FMOFF = 8 * RP;          // tile group 1 = tile rows 4..7 = patch rows +8
+constexpr int MAXPH = 4;
+
+struct Phase {
+  int sh, sw;      // source stride of the sub-lattice (1 or 2)
+  int ph, pw;      // parity offset inside the source
+  int dh0, dw0;    // sub-lattice position of patch row/col 0 relative to the region origin
+};
+
+struct W22Params {
+  rehr_gather_gemm_desc d;
+  int nb_h, nb_w, kchunks, nphase;
+  Phase phase[MAXPH];
+  const float* up;   // U[phase][jd][9][Npad/32][kchunks][4][64][4]
+  uint32_t up_bytes;
+};
+
+// per-axis tap bookkeeping shared by the weight transform and the launcher
+struct AxisPlan {
+  int nph;            // 1 (unit-stride 2-tap axis) or 2 (stride-2 4-tap axis: two source parities)
+  int stride;         // source stride
+  int par[2];         // parity offset per phase
+  int dmin[2];        // patch origin (sub-lattice units)
+  int kidx[2][2];     // weight index of Winograd tap a (= sub-lattice offset dmin + a) per phase
+};
+
+__host__ __device__ inline int floordiv2(int v) { return (v >= 0) ? (v >> 1) : -((1 - v) >> 1); }
+
+__host__ __device__ inline bool plan_axis(const rehr_axis_taps& t, int s, int b, AxisPlan& ap) {
+  if (t.offs != 1 && t.offs != -1) return false;
+  if (s == 1 && t.count == 2) {
+    ap.nph = 1;
+    ap.stride = 1;
+    ap.par[0] = 0;
+    const int o0 = b + t.off0, o1 = b + t.off0 + t.offs;
+    ap.dmin[0] = o0 < o1 ? o0 : o1;
+    ap.kidx[0][o0 - ap.dmin[0]] = t.k0;
+    ap.kidx[0][o1 - ap.dmin[0]] = t.k0 + t.ks;
+    return true;
+  }
+  if (s == 2 && t.count == 4) {
+    ap.nph = 2;
+    ap.stride = 2;
+    for (int p = 0; p < 2; ++p) {       // taps j = p, p + 2
+      const int c = b + t.off0 + t.offs * p;
+      const int base = floordiv2(c);
+      ap.par[p] = c - 2 * base;
+      const int o0 = base, o1 = base + t.offs;   // sub-lattice offsets of the two taps
+      ap.dmin[p] = o0 < o1 ? o0 : o1;
+      ap.kidx[p][o0 - ap.dmin[p]] = t.k0 + t.ks * p;
+      ap.kidx[p][o1 - ap.dmin[p]] = t.k0 + t.ks * (p + 2);
+    }
+    return true;
+  }
+  return false;
+}
+
+// U[phase][jd][xi = r*3+c] = G g G^T of the phase's 2x2 taps, in MFMA fragment order (zero beyond Cin)
+__global__ void w22_weights_kernel(const rehr_gather_gemm_desc d, float* __restrict__ up, int kchunks) {
+  AxisPlan ah, aw;
+  plan_axis(d.th, d.sh, d.bh, ah);
+  plan_axis(d.tw, d.sw, d.bw, aw);
+  const int nphase = ah.nph * aw.nph;
+  const int cpad = kchunks * 32;
+  const int64_t per = (int64_t)d.Npad * cpad;
+  const int64_t per_src = (int64_t)d.Npad * d.Cin;
+  const int64_t total = (int64_t)nphase * d.td.count * per;
+  const int NT = d.Npad / 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pj = (int)(i / per);            // phase * KD + jd
+    const int p = pj / d.td.count, jd = pj - p * d.td.count;
+    const int p_h = p / aw.nph, p_w = p - p_h * aw.nph;
+    const int64_t rem = i - (int64_t)pj * per;
+    const int n = (int)(rem / cpad), ci = (int)(rem - (int64_t)n * cpad);
+    float g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + ah.kidx[p_h][a]) * d.KW + aw.kidx[p_w][b];
+        g[a][b] = ci < d.Cin ? d.wp[(int64_t)wt * per_src + (int64_t)n * d.Cin + ci] : 0.f;
+      }
+    float u[9];
+    u[0] = g[0][0];              u[1] = g[0][0] + g[0][1];                     u[2] = g[0][1];
+    u[3] = g[0][0] + g[1][0];    u[4] = g[0][0] + g[0][1] + g[1][0] + g[1][1]; u[5] = g[0][1] + g[1][1];
+    u[6] = g[1][0];              u[7] = g[1][0] + g[1][1];                     u[8] = g[1][1];
+    const int nt = n >> 5, col = n & 31, chunk = ci >> 5, kk = (ci >> 3) & 3, half = (ci >> 2) & 1, e = ci & 3;
+#pragma unroll
+    for (int x = 0; x < 9; ++x) {
+      const int64_t o = (((((int64_t)pj * 9 + x) * NT + nt) * kchunks + chunk) * 4 + kk) * 256 + (half * 32 + col) * 4 + e;
+      up[o] = u[x];
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
+  const rehr_gather_gemm_desc& d = p.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);  // Winograd row 0..2
+  const int half = lane >> 5, col = lane & 31;
+  const int n_img = blockIdx.z;
+  const int nt0 = blockIdx.y * 2, n0 = blockIdx.y * 64;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int bw_ = b % p.nb_w; b /= p.nb_w;
+  const int bh_ = b % p.nb_h;
+  const int od = b / p.nb_h;
+  const int oh0 = bh_ * 16, ow0 = bw_ * 16;
+
+  // B^T rows (d0 - d1, d1, d2 - d1): R = x[ia] - kb * x[1]
+  const int ia = r;                      // 0, 1, 2
+  const float kb = (r == 1) ? 0.f : 1.f;
+  const int th_ = col >> 3, tw_ = col & 7;
+  // patch column 2*tw_ + j -> slot (j&1)*9 + tw_ + (j>>1)
+  const float* xa = Xs + (2 * th_ + ia) * RP + tw_ * LD + 4 * half;
+  const float* xb = Xs + (2 * th_ + 1) * RP + tw_ * LD + 4 * half;
+
+  // staging pieces (LDS order)
+  int prow[NX], pcol[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int piece = tid + NT_ * i;
+    const int v = piece >> 3;
+    const int ph = (v * 3856) >> 16;          // v / 17 for v < 512
+    const int slot = v - ph * PW;
+    prow[i] = ph;
+    pcol[i] = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
+  }
+  const int pq = tid & 7;
+  const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
+  const int per_phase = p.kchunks * d.td.count;
+  const int items = p.nphase * per_phase;
+  f32x4 rx[NXA];
+  auto fetch = [&](int it, const int lo, const int hi) {
+    const bool live = it < items;
+    const int ii = live ? it : 0;
+    const int ph_i = ii / per_phase;
+    const int rem = ii - ph_i * per_phase;
+    const int jd = rem % d.td.count;
+    const int cc = (rem / d.td.count) * 32;
+    const Phase& P = p.phase[ph_i];
+    const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
+    const bool first = cc < d.c1;
+    const float* src = first ? d.x1 : d.x2;
+    const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
+    const int coff = first ? cc : cc - d.c1;
+    const uint32_t nrec = img_elems * ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(src) + (int64_t)n_img * img_elems * ld, 0, nrec, 0x00020000);
+    const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
+    const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
+#pragma unroll
+    for (int i = lo; i < hi; ++i) {
+      const int piece = tid + NT_ * i;
+      const int ih = (oh0 + P.dh0 + prow[i]) * P.sh + P.ph, iw = (ow0 + P.dw0 + pcol[i]) * P.sw + P.pw;
+      const bool ok = dok & (piece < PVOX * 8) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+      const uint32_t off = base + (uint32_t)(ih * d.Wi + iw) * ld * 4u;
+      rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
+    }
+  };
+  auto stage = [&](int buf, const int lo, const int hi) {
+#pragma unroll
+    for (int i = lo; i < hi; ++i) {
+      const int piece = tid + NT_ * i;
+      const int v = piece >> 3;
+      if (piece < PVOX * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LD + prow[i] * 12 + pq * 4) = rx[i - lo];
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rsu =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
+  const int NT = d.Npad / 32;
+  const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
+  auto load_u = [&](int it, int kk, f32x4 (&ub)[2][3]) {
+    const int ph_i = it / per_phase;
+    const int rem = it - ph_i * per_phase;
+    const int jd = rem % d.td.count;
+    const int chunk = rem / d.td.count;
+    const uint32_t base = (uint32_t)((ph_i * d.td.count + jd) * 9 + r * 3) * xi_stride + (uint32_t)nt0 * nt_stride +
+                          (uint32_t)(chunk * 4 + kk) * 1024u + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        ub[fn][c] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride + fn * nt_stride, 0, 0));
+  };
+
+  f32x16 acc[2][2][3];
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[fm][fn][c][q] = 0.f;
+
+  f32x4 ra[3], rb[3];
+  auto issue_reads = [&](int buf, const int kk, const int fm) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
+      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
+    }
+  };
+  auto combine = [&](f32x4 (&v)[3]) {
+    f32x4 R[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[j] = ra[j] - rb[j] * kb;
+    v[0] = R[0] - R[1];
+    v[1] = R[1];
+    v[2] = R[2] - R[1];
+  };
+  auto mfmas = [&](const int fm, const f32x4 (&v)[3], const f32x4 (&ub)[2][3]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          acc[fm][fn][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[fn][c][e], acc[fm][fn][c], 0, 0, 0);
+  };
+#define W22_MICRO(fm, vcur, vnext, u, ISSUE) \
+  __builtin_amdgcn_sched_barrier(0);         \
+  ISSUE;                                     \
+  mfmas(fm, vcur, u);                        \
+  combine(vnext);                            \
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 VA[3], VB[3], u0[2][3], u1[2][3];
+  fetch(0, 0, NXA);
+  stage(0, 0, NXA);
+  fetch(0, NXA, NX);
+  stage(0, NXA, NX);
+  load_u(0, 0, u0);
+  __syncthreads();
+  issue_reads(0, 0, 0);
+  combine(VA);
+
+  for (int it = 0; it < items; ++it) {
+    const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
+    const int itn = it + 1 < items ? it + 1 : it;
+    W22_MICRO(0, VA, VB, u0, (issue_reads(cur, 0, 1), load_u(it, 1, u1), fetch(it + 1, 0, NXA)))
+    W22_MICRO(1, VB, VA, u0, issue_reads(cur, 1, 0))
+    W22_MICRO(0, VA, VB, u1, (issue_reads(cur, 1, 1), load_u(it, 2, u0), stage(nxt, 0, NXA), fetch(it + 1, NXA, NX)))
+    W22_MICRO(1, VB, VA, u1, issue_reads(cur, 2, 0))
+    W22_MICRO(0, VA, VB, u0, (issue_reads(cur, 2, 1), load_u(it, 3, u1), stage(nxt, NXA, NX)))
+    W22_MICRO(1, VB, VA, u0, issue_reads(cur, 3, 0))
+    W22_MICRO(0, VA, VB, u1, (issue_reads(cur, 3, 1), load_u(itn, 0, u0)))
+    __syncthreads();
+    W22_MICRO(1, VB, VA, u1, issue_reads(nxt, 0, 0))
+  }
+#undef W22_MICRO
+  __syncthreads();
+
+  // ---- output transform Y = A^T M A, A^T = [[1,1,0],[0,1,1]]: columns in registers, rows through LDS
+  float* ex = smem;  // [fm*2+fn][r 3][c' 2][q][lane]
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) {
+      const f32x16 T0 = acc[fm][fn][0] + acc[fm][fn][1];
+      const f32x16 T1 = acc[fm][fn][1] + acc[fm][fn][2];
+      float* e0 = ex + (((fm * 2 + fn) * 3 + r) * 2) * 16 * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        e0[q * 64] = T0[q];
+        e0[(16 + q) * 64] = T1[q];
+      }
+    }
+  __syncthreads();
+  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
+  float ssum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  // 4 output positions (ro, co) over 3 waves: wave w takes position w, wave 0 also position 3
+  for (int pos = r; pos < 4; pos += 3) {
+    const int ro = pos >> 1, co = pos & 1;
+    const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 0.f : 1.f;   // rows: (1,1,0) / (0,1,1)
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) {
+      const int col_n = n0 + fn * 32 + col;
+      const bool colok = col_n < d.Cout;
+      const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
+      float s1_ = 0.f, s2_ = 0.f;
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm) {
+        const float* e0 = ex + ((fm * 2 + fn) * 3 * 2 + co) * 16 * 64 + lane;
+        float t[3][16];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + bv;
+          const float v = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
+          const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
+          const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
+          if (ok)
+            d.y[((((int64_t)n_img * d.Dy + (od * d.osd + d.obd)) * d.Hy + (oh * d.osh + d.obh)) * d.Wy +
+                 (ow * d.osw + d.obw)) * d.ldy + col_n] = v;
+          s1_ += ok ? v : 0.f;
+          s2_ += ok ? v * v : 0.f;
+        }
+      }
+      ssum[fn][0] += s1_ + __shfl_xor(s1_, 32, 64);
+      ssum[fn][1] += s2_ + __shfl_xor(s2_, 32, 64);
+    }
+  }
+  if (d.stats_mode != 0) {
+    __syncthreads();
+    float* red = smem;
+    if (half == 0) {
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn) {
+        red[((r * 2 + fn) * 2 + 0) * 32 + col] = ssum[fn][0];
+        red[((r * 2 + fn) * 2 + 1) * 32 + col] = ssum[fn][1];
+      }
+    }
+    __syncthreads();
+    if (r < 2 && half == 0) {
+      const int fn = r, col_n = n0 + fn * 32 + col;
+      if (col_n < d.Cout) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          a1 += red[((w * 2 + fn) * 2 + 0) * 32 + col];
+          a2 += red[((w * 2 + fn) * 2 + 1) * 32 + col];
+        }
+        double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
+        atomicAdd(st, (double)a1);
+        if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
+      }
+    }
+  }
+}
+
+bool plan22(const rehr_gather_gemm_desc& d, W22Params& p) {
+  static const bool off = getenv("REHR_WINO22") && getenv("REHR_WINO22")[0] == '0';
+  if (off) return false;
+  if (d.sd != 1) return false;
+  AxisPlan ah, aw;
+  if (!plan_axis(d.th, d.sh, d.bh, ah) || !plan_axis(d.tw, d.sw, d.bw, aw)) return false;
+  if (ah.nph != aw.nph) return false;                    // (2-tap, 2-tap) phases or (4-tap, 4-tap) stride-2 gathers
+  if (ah.nph == 2 && (d.osh != 1 || d.osw != 1 || d.obh || d.obw)) return false;
+  if (d.td.count < 1 || d.td.count > 3) return false;
+  if (d.Npad % 64 || d.Lh < 16 || d.Lw < 16) return false;
+  p.nb_h = (d.Lh + 15) / 16;
+  p.nb_w = (d.Lw + 15) / 16;
+  if ((int64_t)p.nb_h * 16 * p.nb_w * 16 * 10 > (int64_t)d.Lh * d.Lw * 13) return false;
+  p.d = d;
+  p.kchunks = (d.Cin + 31) / 32;
+  p.nphase = ah.nph * aw.nph;
+  for (int i = 0; i < ah.nph; ++i)
+    for (int j = 0; j < aw.nph; ++j) {
+      Phase& P = p.phase[i * aw.nph + j];
+      P.sh = ah.stride; P.sw = aw.stride;
+      P.ph = ah.par[i]; P.pw = aw.par[j];
+      P.dh0 = ah.dmin[i]; P.dw0 = aw.dmin[j];
+    }
+  const int64_t need = (int64_t)p.nphase * d.td.count * 9 * d.Npad * p.kchunks * 32 * 4;
+  if (need >= (1ll << 32) - 64) return false;
+  p.up_bytes = (uint32_t)need;
+  const int64_t img = (int64_t)d.Di * d.Hi * d.Wi * 4;
+  if (img * d.ldx1 >= (1ll << 32) - 64 || (d.x2 && img * d.ldx2 >= (1ll << 32) - 64)) return false;
+  if ((int64_t)p.nb_h * p.nb_w * d.Ld >= (1ll << 31) || d.Npad / 64 > 65535 || d.N > 65535) return false;
+  return true;
+}
+
+}  // namespace
+
+int64_t wino22_workspace_bytes(const rehr_gather_gemm_desc& d) {
+  W22Params p;
+  return plan22(d, p) ? (int64_t)p.up_bytes : 0;
+}
+
+int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
+  W22Params p;
+  if (!d.wino_ws || !plan22(d, p)) return REHR_ENOSUP;
+  if (d.wino_ws_bytes < (int64_t)p.up_bytes || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;
+  p.up = d.wino_ws;
+  const int64_t total = (int64_t)p.nphase * d.td.count * d.Npad * p.kchunks * 32;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, p.kchunks);
+  const size_t smem_x = (size_t)2 * BUF * sizeof(float), smem_e = (size_t)4 * 3 * 2 * 16 * 64 * sizeof(float);
+  const size_t smem = smem_x > smem_e ? smem_x : smem_e;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wino22_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        hipSuccess)
+      return REHR_EHIP;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 64, d.N);
+  hipLaunchKernelGGL(wino22_conv_kernel, grid, dim3(NT_), smem, stream, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}

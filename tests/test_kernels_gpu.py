@@ -213,6 +213,43 @@ def test_conv_transpose3d(Cin, Cout, K, stride, pad, dims):
          lambda x, w, b: F.conv_transpose3d(x, w, b, stride, pad), [x, w, b], [True, True, True])
 
 
+WINO22 = [  # transposed convs whose 2x2-tap stride phases / stride-2 input gradient take the F(2x2,2x2) kernel
+    (64, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (1, 3, 16, 16)),
+    (128, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (2, 2, 30, 32)),   # ragged region edges
+    (96, 128, (1, 4, 4), (1, 2, 2), (0, 1, 1), (1, 2, 16, 32)),   # one depth tap, 2 channel tiles
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", WINO22)
+def test_winograd22_conv_transpose(Cin, Cout, K, stride, pad, dims):
+    from rehrseg_amd import hip_backend
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=90)
+    w = _mk(Cin, Cout, *K, seed=91) / (Cin * K[0] * 4) ** 0.5
+    b = _mk(Cout, seed=92)
+    before = hip_backend.wino_launches
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, stride, pad, transposed=True, act=ops.ACT_LRELU, slope=0.2),
+         lambda x, w, b: F.leaky_relu(F.conv_transpose3d(x, w, b, stride, pad), 0.2), [x, w, b], [True, True, True])
+    # 4 forward phases + the stride-2 input gradient (whose 96 output channels pad to 96, not a 64-multiple)
+    assert hip_backend.wino_launches - before == (4 if Cin == 96 else 5)
+
+
+def test_winograd22_virtual_concat_se():
+    """FLAVR upConv3D on a skip concat with the SE statistics epilogue (decoder.{1,2,4})."""
+    x1, x2 = _mk(1, 64, 2, 16, 16, seed=93), _mk(1, 32, 2, 16, 16, seed=94)
+    w = _mk(96, 64, 3, 4, 4, seed=95) / (96 * 12) ** 0.5
+    b = _mk(64, seed=96)
+    aw, ab = _mk(64, 64, 1, 1, 1, seed=97) / 8.0, _mk(64, seed=98)
+
+    def ref(a, c, w, b, aw, ab):
+        v = F.conv_transpose3d(torch.cat([a, c], 1), w, b, (1, 2, 2), (1, 1, 1))
+        return F.leaky_relu(v * torch.sigmoid(F.conv3d(v.mean((2, 3, 4), keepdim=True), aw, ab)), 0.2)
+
+    _run(lambda a, c, w, b, aw, ab: ops.fused_conv3d(a, w, b, (1, 2, 2), (1, 1, 1), x2=c, transposed=True, se=(aw, ab),
+                                                     act=ops.ACT_LRELU, slope=0.2),
+         ref, [x1, x2, w, b, aw, ab], [True, True, True, True, True, True])
+
+
 def test_virtual_concat_conv():
     x1, x2 = _mk(1, 64, 4, 10, 12, seed=7), _mk(1, 128, 4, 10, 12, seed=8)
     w = _mk(64, 192, 3, 3, 3, seed=9) / 72.0
