@@ -10,12 +10,12 @@
 // i.e. B^T = [[1,-1,0],[0,1,0],[0,-1,1]], G = [[1,0],[1,1],[0,1]], A^T = [[1,1,0],[0,1,1]] (all +-1): 9 products
 // per 2 x 2 outputs instead of 16, exact-fp32 MFMA as everywhere else.
 //
-//   block    = 64 tiles (16 x 16 lattice outputs of one depth slice) x 64 channels, 3 waves: wave r =
-//              Winograd row r with 3 columns x 2 tile groups x 2 channel groups = 12 accumulator tiles
+//   block    = 64 tiles (16 x 16 lattice outputs of one depth slice) x 64 channels, 12 waves: wave =
+//              (Winograd row r, tile group, channel group) with 3 accumulator tiles (the row's 3 columns)
 //   K item   = (source phase, 32-channel chunk, depth tap): the 17 x 17 patch of that phase's sub-lattice
 //              in LDS (double-buffered, even/odd column split + row pad: conflict-free fragment reads)
-//   schedule = as wino_conv_big_kernel: micro-steps (k-group, tile group) of 24 MFMAs, next fragments read
-//              and combined underneath, weights one k-group ahead, one barrier per item
+//   schedule = three waves per SIMD hide each other's LDS latency; weights one k-group ahead in
+//              registers, next patch fetched at the top of an item, one barrier per item
 #include "common.h"
 #include "wino_conv.h"
 #include <cstdlib>
@@ -27,9 +27,8 @@ constexpr int PW = 17;                 // patch is 17 x 17
 constexpr int RP = PW * LD + 12;       // row pitch: two rows = 32 floats mod 64
 constexpr int BUF = PW * RP;           // floats per slice buffer
 constexpr int PVOX = PW * PW;          // 289
-constexpr int NT_ = 192;               // threads
-constexpr int NX = (PVOX * 8 + NT_ - 1) / NT_;  // 13 pieces per thread
-constexpr int NXA = 7;
+constexpr int NT_ = 768;               // threads: 12 waves
+constexpr int NX = (PVOX * 8 + NT_ - 1) / NT_;  // 4 pieces per thread
 constexpr int FMOFF = 8 * RP;          // tile group 1 = tile rows 4..7 = patch rows +8
 constexpr int MAXPH = 4;
 
@@ -130,11 +129,14 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;
 
+  // 12 waves = 3 Winograd rows x 2 tile groups x 2 channel groups: three waves per SIMD (9 points do not
+  // divide over 4 SIMDs any other way -- the 3-wave version left one SIMD idle), 3 accumulator tiles each
   const int tid = threadIdx.x, lane = tid & 63;
-  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);  // Winograd row 0..2
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = wv % 3, fm = (wv / 3) & 1, fn = wv / 6;
   const int half = lane >> 5, col = lane & 31;
   const int n_img = blockIdx.z;
-  const int nt0 = blockIdx.y * 2, n0 = blockIdx.y * 64;
+  const int nt0 = blockIdx.y * 2 + fn, n0 = blockIdx.y * 64;
   int b = xcd_remap(blockIdx.x, gridDim.x);
   const int bw_ = b % p.nb_w; b /= p.nb_w;
   const int bh_ = b % p.nb_h;
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   const int oh0 = bh_ * 16, ow0 = bw_ * 16;
 
   // B^T rows (d0 - d1, d1, d2 - d1): R = x[ia] - kb * x[1]
-  const int ia = r;                      // 0, 1, 2
+  const int ia = r;
   const float kb = (r == 1) ? 0.f : 1.f;
-  const int th_ = col >> 3, tw_ = col & 7;
+  const int th_ = fm * 4 + (col >> 3), tw_ = col & 7;
   // patch column 2*tw_ + j -> slot (j&1)*9 + tw_ + (j>>1)
   const float* xa = Xs + (2 * th_ + ia) * RP + tw_ * LD + 4 * half;
   const float* xb = Xs + (2 * th_ + 1) * RP + tw_ * LD + 4 * half;
@@ -164,8 +166,8 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
   const int per_phase = p.kchunks * d.td.count;
   const int items = p.nphase * per_phase;
-  f32x4 rx[NXA];
-  auto fetch = [&](int it, const int lo, const int hi) {
+  f32x4 rx[NX];
+  auto fetch = [&](int it) {
     const bool live = it < items;
     const int ii = live ? it : 0;
     const int ph_i = ii / per_phase;
@@ -184,20 +186,20 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
     const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
     const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
 #pragma unroll
-    for (int i = lo; i < hi; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int piece = tid + NT_ * i;
       const int ih = (oh0 + P.dh0 + prow[i]) * P.sh + P.ph, iw = (ow0 + P.dw0 + pcol[i]) * P.sw + P.pw;
       const bool ok = dok & (piece < PVOX * 8) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
       const uint32_t off = base + (uint32_t)(ih * d.Wi + iw) * ld * 4u;
-      rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
     }
   };
-  auto stage = [&](int buf, const int lo, const int hi) {
+  auto stage = [&](int buf) {
 #pragma unroll
-    for (int i = lo; i < hi; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int piece = tid + NT_ * i;
       const int v = piece >> 3;
-      if (piece < PVOX * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LD + prow[i] * 12 + pq * 4) = rx[i - lo];
+      if (piece < PVOX * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LD + prow[i] * 12 + pq * 4) = rx[i];
     }
   };
 
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
   const int NT = d.Npad / 32;
   const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
-  auto load_u = [&](int it, int kk, f32x4 (&ub)[2][3]) {
+  auto load_u = [&](int it, int kk, f32x4 (&ub)[3]) {
     const int ph_i = it / per_phase;
     const int rem = it - ph_i * per_phase;
     const int jd = rem % d.td.count;
@@ -213,155 +215,118 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
     const uint32_t base = (uint32_t)((ph_i * d.td.count + jd) * 9 + r * 3) * xi_stride + (uint32_t)nt0 * nt_stride +
                           (uint32_t)(chunk * 4 + kk) * 1024u + (uint32_t)lane * 16u;
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        ub[fn][c] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride + fn * nt_stride, 0, 0));
+    for (int c = 0; c < 3; ++c)
+      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride, 0, 0));
   };
 
-  f32x16 acc[2][2][3];
+  f32x16 acc[3];
 #pragma unroll
-  for (int fm = 0; fm < 2; ++fm)
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[fm][fn][c][q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
 
-  f32x4 ra[3], rb[3];
-  auto issue_reads = [&](int buf, const int kk, const int fm) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
-      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
-    }
-  };
-  auto combine = [&](f32x4 (&v)[3]) {
+  auto kstep = [&](int buf, const int kk, const f32x4 (&ub)[3]) {
     f32x4 R[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) R[j] = ra[j] - rb[j] * kb;
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
+      R[j] = a - bq * kb;
+    }
+    f32x4 v[3];
     v[0] = R[0] - R[1];
     v[1] = R[1];
     v[2] = R[2] - R[1];
-  };
-  auto mfmas = [&](const int fm, const f32x4 (&v)[3], const f32x4 (&ub)[2][3]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          acc[fm][fn][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[fn][c][e], acc[fm][fn][c], 0, 0, 0);
+      for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
   };
-#define W22_MICRO(fm, vcur, vnext, u, ISSUE) \
-  __builtin_amdgcn_sched_barrier(0);         \
-  ISSUE;                                     \
-  mfmas(fm, vcur, u);                        \
-  combine(vnext);                            \
-  __builtin_amdgcn_sched_barrier(0);
 
-  f32x4 VA[3], VB[3], u0[2][3], u1[2][3];
-  fetch(0, 0, NXA);
-  stage(0, 0, NXA);
-  fetch(0, NXA, NX);
-  stage(0, NXA, NX);
+  // item loop: weights one k-group ahead in registers, next item's patch fetched at the top and written to
+  // the other LDS slice at the bottom; the three waves of a SIMD hide each other's LDS latency
+  f32x4 u0[3], u1[3];
+  fetch(0);
   load_u(0, 0, u0);
+  stage(0);
   __syncthreads();
-  issue_reads(0, 0, 0);
-  combine(VA);
-
   for (int it = 0; it < items; ++it) {
     const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
     const int itn = it + 1 < items ? it + 1 : it;
-    W22_MICRO(0, VA, VB, u0, (issue_reads(cur, 0, 1), load_u(it, 1, u1), fetch(it + 1, 0, NXA)))
-    W22_MICRO(1, VB, VA, u0, issue_reads(cur, 1, 0))
-    W22_MICRO(0, VA, VB, u1, (issue_reads(cur, 1, 1), load_u(it, 2, u0), stage(nxt, 0, NXA), fetch(it + 1, NXA, NX)))
-    W22_MICRO(1, VB, VA, u1, issue_reads(cur, 2, 0))
-    W22_MICRO(0, VA, VB, u0, (issue_reads(cur, 2, 1), load_u(it, 3, u1), stage(nxt, NXA, NX)))
-    W22_MICRO(1, VB, VA, u0, issue_reads(cur, 3, 0))
-    W22_MICRO(0, VA, VB, u1, (issue_reads(cur, 3, 1), load_u(itn, 0, u0)))
+    fetch(it + 1);
+    load_u(it, 1, u1);
+    kstep(cur, 0, u0);
+    load_u(it, 2, u0);
+    kstep(cur, 1, u1);
+    load_u(it, 3, u1);
+    kstep(cur, 2, u0);
+    load_u(itn, 0, u0);
+    kstep(cur, 3, u1);
+    stage(nxt);
     __syncthreads();
-    W22_MICRO(1, VB, VA, u1, issue_reads(nxt, 0, 0))
   }
-#undef W22_MICRO
-  __syncthreads();
 
   // ---- output transform Y = A^T M A, A^T = [[1,1,0],[0,1,1]]: columns in registers, rows through LDS
   float* ex = smem;  // [fm*2+fn][r 3][c' 2][q][lane]
+  {
+    const f32x16 T0 = acc[0] + acc[1];
+    const f32x16 T1 = acc[1] + acc[2];
+    float* e0 = ex + (((fm * 2 + fn) * 3 + r) * 2) * 16 * 64 + lane;
 #pragma unroll
-  for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-    for (int fn = 0; fn < 2; ++fn) {
-      const f32x16 T0 = acc[fm][fn][0] + acc[fm][fn][1];
-      const f32x16 T1 = acc[fm][fn][1] + acc[fm][fn][2];
-      float* e0 = ex + (((fm * 2 + fn) * 3 + r) * 2) * 16 * 64 + lane;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        e0[q * 64] = T0[q];
-        e0[(16 + q) * 64] = T1[q];
-      }
+    for (int q = 0; q < 16; ++q) {
+      e0[q * 64] = T0[q];
+      e0[(16 + q) * 64] = T1[q];
     }
+  }
   __syncthreads();
   const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
-  float ssum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  // 4 output positions (ro, co) over 3 waves: wave w takes position w, wave 0 also position 3
+  const int col_n = n0 + fn * 32 + col;
+  const bool colok = col_n < d.Cout;
+  const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
+  float s1_ = 0.f, s2_ = 0.f;
+  // the wave's (tile group, channel group): output positions (ro, co) = r, and r + 3 for wave row 0
   for (int pos = r; pos < 4; pos += 3) {
     const int ro = pos >> 1, co = pos & 1;
     const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 0.f : 1.f;   // rows: (1,1,0) / (0,1,1)
+    const float* e0 = ex + ((fm * 2 + fn) * 3 * 2 + co) * 16 * 64 + lane;
+    float t[3][16];
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn) {
-      const int col_n = n0 + fn * 32 + col;
-      const bool colok = col_n < d.Cout;
-      const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
-      float s1_ = 0.f, s2_ = 0.f;
+    for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-      for (int fm = 0; fm < 2; ++fm) {
-        const float* e0 = ex + ((fm * 2 + fn) * 3 * 2 + co) * 16 * 64 + lane;
-        float t[3][16];
+      for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + bv;
-          const float v = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
-          const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
-          const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
-          if (ok)
-            d.y[((((int64_t)n_img * d.Dy + (od * d.osd + d.obd)) * d.Hy + (oh * d.osh + d.obh)) * d.Wy +
-                 (ow * d.osw + d.obw)) * d.ldy + col_n] = v;
-          s1_ += ok ? v : 0.f;
-          s2_ += ok ? v * v : 0.f;
-        }
-      }
-      ssum[fn][0] += s1_ + __shfl_xor(s1_, 32, 64);
-      ssum[fn][1] += s2_ + __shfl_xor(s2_, 32, 64);
+    for (int q = 0; q < 16; ++q) {
+      const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + bv;
+      const float v = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
+      const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
+      const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
+      if (ok)
+        d.y[((((int64_t)n_img * d.Dy + (od * d.osd + d.obd)) * d.Hy + (oh * d.osh + d.obh)) * d.Wy +
+             (ow * d.osw + d.obw)) * d.ldy + col_n] = v;
+      s1_ += ok ? v : 0.f;
+      s2_ += ok ? v * v : 0.f;
     }
   }
-  if (d.stats_mode != 0) {
+  if (d.stats_mode != 0) {  // block-level sums first: one atomic per column and block
+    s1_ += __shfl_xor(s1_, 32, 64);
+    s2_ += __shfl_xor(s2_, 32, 64);
     __syncthreads();
-    float* red = smem;
+    float* red = smem;  // [wave 12][2][32]
     if (half == 0) {
-#pragma unroll
-      for (int fn = 0; fn < 2; ++fn) {
-        red[((r * 2 + fn) * 2 + 0) * 32 + col] = ssum[fn][0];
-        red[((r * 2 + fn) * 2 + 1) * 32 + col] = ssum[fn][1];
-      }
+      red[(wv * 2 + 0) * 32 + col] = s1_;
+      red[(wv * 2 + 1) * 32 + col] = s2_;
     }
     __syncthreads();
-    if (r < 2 && half == 0) {
-      const int fn = r, col_n = n0 + fn * 32 + col;
-      if (col_n < d.Cout) {
+    if (wv < 2 && half == 0) {  // wave fn' sums the six (row, tile group) partials of its 32 columns
+      const int fq = wv, cn = n0 + fq * 32 + col;
+      if (cn < d.Cout) {
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          a1 += red[((w * 2 + fn) * 2 + 0) * 32 + col];
-          a2 += red[((w * 2 + fn) * 2 + 1) * 32 + col];
+        for (int w6 = 0; w6 < 6; ++w6) {
+          a1 += red[((fq * 6 + w6) * 2 + 0) * 32 + col];
+          a2 += red[((fq * 6 + w6) * 2 + 1) * 32 + col];
         }
-        double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
+        double* st = d.stats + ((int64_t)n_img * d.Cout + cn) * 2;
         atomicAdd(st, (double)a1);
         if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
       }
