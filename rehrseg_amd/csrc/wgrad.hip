@@ -376,6 +376,8 @@ extern "C" int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* dp) {
   if (rc != REHR_OK) return rc;
   const int64_t wino = wino_wgrad_workspace_bytes(d);
   if (wino > 0) return wino;
+  const int64_t wino22 = wino22_wgrad_workspace_bytes(d);
+  if (wino22 > 0) return wino22;
   BrickPlanOut bo;
   WGParams pb = p;
   if (wgrad_brick_plan(d, pb, bo)) return ws_bytes(pb);
@@ -388,7 +390,7 @@ extern "C" int rehr_wgrad_uses_winograd(const rehr_wgrad_desc* dp) {
   rehr_wgrad_desc d = *dp;
   if (!d.dst) d.dst = reinterpret_cast<float*>(16);
   if (plan(d, p) != REHR_OK) return 0;
-  return wino_wgrad_workspace_bytes(d) > 0 ? 1 : 0;
+  return (wino_wgrad_workspace_bytes(d) > 0 || wino22_wgrad_workspace_bytes(d) > 0) ? 1 : 0;
 }
 
 extern "C" int rehr_wgrad_f32(const rehr_wgrad_desc* dp, void* stream) {
@@ -397,6 +399,8 @@ extern "C" int rehr_wgrad_f32(const rehr_wgrad_desc* dp, void* stream) {
   int rc = plan(*dp, p);
   if (rc != REHR_OK) return rc;
   rc = wino_wgrad_try(*dp, (hipStream_t)stream);  // 2.25x fewer multiplications where it applies
+  if (rc != REHR_ENOSUP) return rc;
+  rc = wino22_wgrad_try(*dp, (hipStream_t)stream);  // stride-2 4-tap transposed convs: 1.78x fewer
   if (rc != REHR_ENOSUP) return rc;
   BrickPlanOut bo;
   const bool brick = wgrad_brick_plan(*dp, p, bo);  // overrides tiles / splits / slab geometry when it applies

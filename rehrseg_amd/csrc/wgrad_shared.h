@@ -33,3 +33,6 @@ int wgrad_brick_launch(const WGParams& w, const BrickPlanOut& o, hipStream_t str
 // Winograd weight gradient (wino_wgrad.hip): tried first for unit-stride 3x3 (H, W) taps
 int64_t wino_wgrad_workspace_bytes(const rehr_wgrad_desc& d);  // 0 = not applicable
 int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream);
+// F(2x2,2x2) weight gradient of stride-2 4-tap transposed convolutions (wino22_wgrad.hip)
+int64_t wino22_wgrad_workspace_bytes(const rehr_wgrad_desc& d);  // 0 = not applicable
+int wino22_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream);

@@ -18,6 +18,7 @@
 //              registers, next patch fetched at the top of an item, one barrier per item
 #include "common.h"
 #include "wino_conv.h"
+#include "wino22_shared.h"
 #include <cstdlib>
 
 namespace {
@@ -45,46 +46,6 @@ struct W22Params {
   const float* up;   // U[phase][jd][9][Npad/32][kchunks][4][64][4]
   uint32_t up_bytes;
 };
-
-// per-axis tap bookkeeping shared by the weight transform and the launcher
-struct AxisPlan {
-  int nph;            // 1 (unit-stride 2-tap axis) or 2 (stride-2 4-tap axis: two source parities)
-  int stride;         // source stride
-  int par[2];         // parity offset per phase
-  int dmin[2];        // patch origin (sub-lattice units)
-  int kidx[2][2];     // weight index of Winograd tap a (= sub-lattice offset dmin + a) per phase
-};
-
-__host__ __device__ inline int floordiv2(int v) { return (v >= 0) ? (v >> 1) : -((1 - v) >> 1); }
-
-__host__ __device__ inline bool plan_axis(const rehr_axis_taps& t, int s, int b, AxisPlan& ap) {
-  if (t.offs != 1 && t.offs != -1) return false;
-  if (s == 1 && t.count == 2) {
-    ap.nph = 1;
-    ap.stride = 1;
-    ap.par[0] = 0;
-    const int o0 = b + t.off0, o1 = b + t.off0 + t.offs;
-    ap.dmin[0] = o0 < o1 ? o0 : o1;
-    ap.kidx[0][o0 - ap.dmin[0]] = t.k0;
-    ap.kidx[0][o1 - ap.dmin[0]] = t.k0 + t.ks;
-    return true;
-  }
-  if (s == 2 && t.count == 4) {
-    ap.nph = 2;
-    ap.stride = 2;
-    for (int p = 0; p < 2; ++p) {       // taps j = p, p + 2
-      const int c = b + t.off0 + t.offs * p;
-      const int base = floordiv2(c);
-      ap.par[p] = c - 2 * base;
-      const int o0 = base, o1 = base + t.offs;   // sub-lattice offsets of the two taps
-      ap.dmin[p] = o0 < o1 ? o0 : o1;
-      ap.kidx[p][o0 - ap.dmin[p]] = t.k0 + t.ks * p;
-      ap.kidx[p][o1 - ap.dmin[p]] = t.k0 + t.ks * (p + 2);
-    }
-    return true;
-  }
-  return false;
-}
 
 // U[phase][jd][xi = r*3+c] = G g G^T of the phase's 2x2 taps, in MFMA fragment order (zero beyond Cin)
 __global__ void w22_weights_kernel(const rehr_gather_gemm_desc d, float* __restrict__ up, int kchunks) {

@@ -227,9 +227,10 @@ def test_winograd22_conv_transpose(Cin, Cout, K, stride, pad, dims):
     x = _mk(N, Cin, D, H, W, seed=90)
     w = _mk(Cin, Cout, *K, seed=91) / (Cin * K[0] * 4) ** 0.5
     b = _mk(Cout, seed=92)
-    before = hip_backend.wino_launches
+    before, before_w = hip_backend.wino_launches, hip_backend.wino_wgrad_launches
     _run(lambda x, w, b: ops.fused_conv3d(x, w, b, stride, pad, transposed=True, act=ops.ACT_LRELU, slope=0.2),
          lambda x, w, b: F.leaky_relu(F.conv_transpose3d(x, w, b, stride, pad), 0.2), [x, w, b], [True, True, True])
+    assert hip_backend.wino_wgrad_launches - before_w == 1, "the weight gradient takes the F(2x2,2x2) kernel too"
     # 4 forward phases + the stride-2 input gradient (whose 96 output channels pad to 96, not a 64-multiple)
     assert hip_backend.wino_launches - before == (4 if Cin == 96 else 5)
 
