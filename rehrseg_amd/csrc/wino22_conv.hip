@@ -104,9 +104,8 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   const int od = b / p.nb_h;
   const int oh0 = bh_ * 16, ow0 = bw_ * 16;
 
-  // B^T rows (d0 - d1, d1, d2 - d1): R = x[ia] - kb * x[1]
+  // B^T rows (d0 - d1, d1, d2 - d1): R = x[ia] (- x[1] unless ia == 1)
   const int ia = r;
-  const float kb = (r == 1) ? 0.f : 1.f;
   const int th_ = fm * 4 + (col >> 3), tw_ = col & 7;
   // patch column 2*tw_ + j -> slot (j&1)*9 + tw_ + (j>>1)
   const float* xa = Xs + (2 * th_ + ia) * RP + tw_ * LD + 4 * half;
@@ -128,13 +127,19 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   const int per_phase = p.kchunks * d.td.count;
   const int items = p.nphase * per_phase;
   f32x4 rx[NX];
-  auto fetch = [&](int it) {
-    const bool live = it < items;
-    const int ii = live ? it : 0;
-    const int ph_i = ii / per_phase;
-    const int rem = ii - ph_i * per_phase;
-    const int jd = rem % d.td.count;
-    const int cc = (rem / d.td.count) * 32;
+  // items are walked with counters (phase, chunk, depth tap): no integer division in the loop
+  struct Item { int ph, chunk, jd; };
+  auto advance = [&](Item& t) {
+    if (++t.jd == d.td.count) {
+      t.jd = 0;
+      if (++t.chunk == p.kchunks) { t.chunk = 0; ++t.ph; }
+    }
+  };
+  auto fetch = [&](const Item& t) {
+    const bool live = t.ph < p.nphase;
+    const int ph_i = live ? t.ph : 0;
+    const int jd = t.jd;
+    const int cc = t.chunk * 32;
     const Phase& P = p.phase[ph_i];
     const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
     const bool first = cc < d.c1;
@@ -168,13 +173,10 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
   const int NT = d.Npad / 32;
   const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
-  auto load_u = [&](int it, int kk, f32x4 (&ub)[3]) {
-    const int ph_i = it / per_phase;
-    const int rem = it - ph_i * per_phase;
-    const int jd = rem % d.td.count;
-    const int chunk = rem / d.td.count;
-    const uint32_t base = (uint32_t)((ph_i * d.td.count + jd) * 9 + r * 3) * xi_stride + (uint32_t)nt0 * nt_stride +
-                          (uint32_t)(chunk * 4 + kk) * 1024u + (uint32_t)lane * 16u;
+  const uint32_t ulane = (uint32_t)(r * 3) * xi_stride + (uint32_t)nt0 * nt_stride + (uint32_t)lane * 16u;
+  auto load_u = [&](const Item& t, int kk, f32x4 (&ub)[3]) {
+    const int ph_i = t.ph < p.nphase ? t.ph : 0;  // (one item past the end is requested and never used)
+    const uint32_t base = (uint32_t)((ph_i * d.td.count + t.jd) * 9) * xi_stride + (uint32_t)(t.chunk * 4 + kk) * 1024u + ulane;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride, 0, 0));
@@ -189,10 +191,10 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   auto kstep = [&](int buf, const int kk, const f32x4 (&ub)[3]) {
     f32x4 R[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
-      R[j] = a - bq * kb;
+    for (int j = 0; j < 3; ++j) R[j] = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
+    if (r != 1) {  // wave-uniform: the middle Winograd row is the patch row itself
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[j] -= *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
     }
     f32x4 v[3];
     v[0] = R[0] - R[1];
@@ -207,23 +209,25 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   // item loop: weights one k-group ahead in registers, next item's patch fetched at the top and written to
   // the other LDS slice at the bottom; the three waves of a SIMD hide each other's LDS latency
   f32x4 u0[3], u1[3];
-  fetch(0);
-  load_u(0, 0, u0);
+  Item cur_i = {0, 0, 0}, nxt_i = {0, 0, 0};
+  fetch(cur_i);
+  load_u(cur_i, 0, u0);
   stage(0);
   __syncthreads();
   for (int it = 0; it < items; ++it) {
     const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
-    const int itn = it + 1 < items ? it + 1 : it;
-    fetch(it + 1);
-    load_u(it, 1, u1);
+    advance(nxt_i);
+    fetch(nxt_i);
+    load_u(cur_i, 1, u1);
     kstep(cur, 0, u0);
-    load_u(it, 2, u0);
+    load_u(cur_i, 2, u0);
     kstep(cur, 1, u1);
-    load_u(it, 3, u1);
+    load_u(cur_i, 3, u1);
     kstep(cur, 2, u0);
-    load_u(itn, 0, u0);
+    load_u(nxt_i, 0, u0);
     kstep(cur, 3, u1);
     stage(nxt);
+    cur_i = nxt_i;
     __syncthreads();
   }
 

@@ -66,13 +66,25 @@ __global__ __launch_bounds__(NTH) void wino22_wgrad_kernel(const WW22Params p) {
   const int64_t l_img = (int64_t)d.Ld * d.Lh * d.Lw * d.ldl, g_img = (int64_t)d.Dg * d.Hg * d.Wg * d.ldg;
   const uint32_t l_bytes = (uint32_t)(l_img * 4), g_bytes = (uint32_t)(g_img * 4);
   f32x4 ry[2], rx[2], rt;
+  // the stage walk keeps (region column, region row, depth, sample) counters: one division chain per block
+  int s_bw, s_bh, s_od, s_n;
+  {
+    int it = it0;
+    s_bw = it % p.nb_w; it /= p.nb_w;
+    s_bh = it % p.nb_h; it /= p.nb_h;
+    s_od = it % d.Ld;
+    s_n = it / d.Ld;
+  }
   auto fetch = [&](int st) {
     const bool live = st < nstages;
-    int it = it0 + (live ? st : 0);
-    const int bw_ = it % p.nb_w; it /= p.nb_w;
-    const int bh_ = it % p.nb_h; it /= p.nb_h;
-    const int od = it % d.Ld;
-    const int n = it / d.Ld;
+    const int bw_ = s_bw, bh_ = s_bh, od = s_od, n = live ? s_n : 0;
+    if (++s_bw == p.nb_w) {
+      s_bw = 0;
+      if (++s_bh == p.nb_h) {
+        s_bh = 0;
+        if (++s_od == d.Ld) { s_od = 0; ++s_n; }
+      }
+    }
     const int oh0 = bh_ * RH, ow0 = bw_ * RW;
     const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
