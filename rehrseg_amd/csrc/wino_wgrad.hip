@@ -10,10 +10,11 @@
 //             region) items (split-K, slabs reduced deterministically afterwards)
 //   wave r  = Winograd row r: 4 columns x (2 x 2) 32x32 tiles = 16 accumulator tiles in AGPRs
 //             (one wave per SIMD, full register file -- all latency hiding is explicit)
-//   stage   = one region: dY (4 x 16 voxels) and the x patch (6 x 18) in LDS, voxel-major as
-//             they sit in HBM (channels contiguous, rows padded to 68 floats: the two wave halves
-//             land on disjoint bank halves).  The MFMA k index is the TILE, so operands are read
-//             as scalars (ds_read_b32, lane = channel) and transformed in registers.
+//   stage   = one region: dY (4 x 16 voxels) and the x patch (6 x 18) in LDS, TRANSPOSED while
+//             staging to [row][channel][column] (scalar stores, 16 columns x 4 channel quads per
+//             wave instruction = 64 distinct banks).  The MFMA k index is the TILE, so a lane
+//             (= channel) needs 8 / 10 consecutive columns per row: two or three 128/64-bit reads
+//             instead of 8 / 10 scalar ones (20 LDS reads per k-group instead of 72).
 //   k-group = 8 tiles (one tile row): 4 quarters (fa, fb) of 16 MFMAs; the operands of the next
 //             k-group are read + transformed one set per quarter, slotted between the MFMAs.
 #include "common.h"
@@ -40,10 +41,15 @@ struct WWParams {
 // file; smaller shapes for 32-channel layers run several blocks per CU).
 template <int FA, int FB>
 struct WWCfg {
-  static constexpr int LDY = FA * 32 + 4, LDX = FB * 32 + 4;  // row pitch: wave halves on disjoint banks
-  static constexpr int YBUF = YV * LDY, XBUF = XV * LDX, BUF = YBUF + XBUF;
-  static constexpr int QY = FA * 8, QX = FB * 8;             // 16-byte pieces per voxel
-  static constexpr int NPY = YV * QY / 256, NPX = (XV * QX + 255) / 256, NP = NPY + NPX;
+  // LDS holds both operands TRANSPOSED, [row][channel][column] with a 20-float column pitch: a lane
+  // (= channel) reads its 8 / 10 consecutive columns as 128-bit words (5 groups of 4 banks between
+  // neighbouring channels: conflict-free), 20 reads per k-group instead of 72 scalar ones
+  static constexpr int WP = 20;
+  static constexpr int CA = FA * 32, CG = FB * 32;
+  static constexpr int YBUF = RH * CA * WP, XBUF = XH * CG * WP, BUF = YBUF + XBUF;
+  // staging pieces per thread: a wave instruction covers 16 columns x 4 channel quads of one (row, quad
+  // group) -> 64 distinct banks for each of the 4 scalar stores of a piece
+  static constexpr int NPY = 2 * FA, NPXM = 3 * FB, NP = NPY + NPXM + 1;
   static constexpr int NPA = (NP + 1) / 2;
   static constexpr int NQ = FA * FB, NPREP = FA + FB;
   static constexpr int MINB = (FA * FB == 4) ? 1 : ((FA * FB == 2) ? 1 : 2);
@@ -52,8 +58,8 @@ struct WWCfg {
 template <int FA, int FB>
 __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(const WWParams p) {
   using C = WWCfg<FA, FB>;
-  constexpr int LDY = C::LDY, LDX = C::LDX, YBUF = C::YBUF, BUF = C::BUF;
-  constexpr int NPY = C::NPY, NP = C::NP, NPA = C::NPA;
+  constexpr int WP = C::WP, CA = C::CA, CG = C::CG, YBUF = C::YBUF, BUF = C::BUF;
+  constexpr int NPY = C::NPY, NPXM = C::NPXM, NP = C::NP, NPA = C::NPA;
   const rehr_wgrad_desc& d = p.d;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -74,15 +80,26 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
   const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
   const float s2 = (r == 1) ? 1.f : -1.f;
 
-  // ---- staging pieces (16-byte pieces, QY / QX per voxel)
-  const int qy = tid & (C::QY - 1), qx = tid & (C::QX - 1);
-  const int vy0 = tid / C::QY, vx0 = tid / C::QX;          // first voxel of this thread
-  constexpr int VYS = 256 / C::QY, VXS = 256 / C::QX;      // voxel step between its pieces
+  // ---- staging pieces: lane = (column w16, quad ql) of the wave's (row, quad group) combo
+  const int wv = r;  // wave index doubles as the staging wave id
+  const int w16 = lane & 15, ql = lane >> 4;
   const int64_t l_img = (int64_t)d.Ld * d.Lh * d.Lw * d.ldl, g_img = (int64_t)d.Dg * d.Hg * d.Wg * d.ldg;
   const uint32_t l_bytes = (uint32_t)(l_img * 4), g_bytes = (uint32_t)(g_img * 4);
-  const bool yq_ok = (ca0 + 4 * qy) < d.Ca, xq_ok = (cg0 + 4 * qx) < d.Cg;
   f32x4 rx[NPA];
-  auto fetch = [&](int st, const int lo, const int hi) {  // pieces [lo, hi) of stage st: Y pieces first
+  // piece i -> (kind, row, column, quad): 0 = dY tile, 1 = x patch
+  auto piece = [&](const int i, int& kind, int& row, int& cw, int& q) {
+    if (i < NPY) {
+      const int combo = wv + 4 * i;
+      kind = 0; row = combo / (2 * FA); q = (combo % (2 * FA)) * 4 + ql; cw = w16;
+    } else if (i < NPY + NPXM) {
+      const int combo = wv + 4 * (i - NPY);
+      kind = 1; row = combo / (2 * FB); q = (combo % (2 * FB)) * 4 + ql; cw = w16;
+    } else {  // patch columns 16, 17: 6 rows x 2 columns x 8*FB quads on the first 96*FB threads
+      const int rest = tid / (8 * FB);
+      kind = (tid < 96 * FB) ? 1 : 2; row = rest >> 1; cw = 16 + (rest & 1); q = tid % (8 * FB);
+    }
+  };
+  auto fetch = [&](int st, const int lo, const int hi) {  // pieces [lo, hi) of stage st
     const bool live = st < nstages;
     int it = it0 + (live ? st : 0);
     const int bw_ = it % p.nb_w; it /= p.nb_w;
@@ -98,18 +115,18 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
     const bool dok = live & ((unsigned)id < (unsigned)d.Dg);
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
+      int kind, row, cw, q;
+      piece(i, kind, row, cw, q);
       if (i < NPY) {
-        const int vox = vy0 + VYS * i;  // 0..63
-        const int gh = oh0 + (vox >> 4), gw = ow0 + (vox & 15);
-        const bool ok = live & yq_ok & (gh < d.Lh) & (gw < d.Lw);
-        const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * qy) * 4u;
+        const int gh = oh0 + row, gw = ow0 + cw;
+        const bool ok = live & ((ca0 + 4 * q) < d.Ca) & (gh < d.Lh) & (gw < d.Lw);
+        const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * q) * 4u;
         rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : l_bytes, 0, 0));
       } else {
-        const int vox = vx0 + VXS * (i - NPY);  // valid < 108
-        const int row = vox / XW, cw = vox - row * XW;
         const int ih = oh0 - 1 + row, iw = ow0 - 1 + cw;
-        const bool ok = dok & xq_ok & (vox < XV) & ((unsigned)ih < (unsigned)d.Hg) & ((unsigned)iw < (unsigned)d.Wg);
-        const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * qx) * 4u;
+        const bool ok = dok & (kind == 1) & ((cg0 + 4 * q) < d.Cg) & ((unsigned)ih < (unsigned)d.Hg) &
+                        ((unsigned)iw < (unsigned)d.Wg);
+        const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * q) * 4u;
         rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : g_bytes, 0, 0));
       }
     }
@@ -117,12 +134,16 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
   auto stage = [&](int buf, const int lo, const int hi) {
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
+      int kind, row, cw, q;
+      piece(i, kind, row, cw, q);
       if (i < NPY) {
-        const int vox = vy0 + VYS * i;
-        *reinterpret_cast<f32x4*>(smem + buf + vox * LDY + 4 * qy) = rx[i - lo];
-      } else {
-        const int vox = vx0 + VXS * (i - NPY);
-        if (vox < XV) *reinterpret_cast<f32x4*>(smem + buf + YBUF + vox * LDX + 4 * qx) = rx[i - lo];
+        float* dst = smem + buf + (row * CA + 4 * q) * WP + cw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e * WP] = rx[i - lo][e];
+      } else if (kind == 1) {
+        float* dst = smem + buf + YBUF + (row * CG + 4 * q) * WP + cw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e * WP] = rx[i - lo][e];
       }
     }
   };
@@ -131,15 +152,20 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
 #pragma unroll
   for (int fa = 0; fa < FA; ++fa) bsum[fa] = 0.f;
   // ---- operand preparation for one k-group (tile row g of the region)
-  // Z[c][e] for 32 co: tiles 4*half + e, dY rows 2g, 2g+1, columns 2*tile + {0,1}
-  const float* ybase = smem + (8 * half) * LDY + col;
-  const float* xbase = smem + YBUF + (8 * half) * LDX + col;
+  // Z[c][e] for 32 co: tiles 4*half + e, dY rows 2g, 2g+1, columns 8*half .. 8*half + 7
+  const float* ybase = smem + col * WP + 8 * half;
+  const float* xbase = smem + YBUF + col * WP + 8 * half;
   auto prep_z = [&](int buf, const int g, const int fa, f32x4 (&Z)[4]) {
-    const float* y0 = ybase + buf + (2 * g) * RW * LDY + fa * 32;
-    const float* y1 = y0 + RW * LDY;
+    const float* y0 = ybase + buf + ((2 * g) * CA + fa * 32) * WP;
+    const float* y1 = y0 + CA * WP;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(y0), a1 = *reinterpret_cast<const f32x4*>(y0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(y1), b1 = *reinterpret_cast<const f32x4*>(y1 + 4);
     float z[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) z[k] = zka * y0[k * LDY] + zkb * y1[k * LDY];
+    for (int k = 0; k < 4; ++k) {
+      z[k] = zka * a0[k] + zkb * b0[k];
+      z[4 + k] = zka * a1[k] + zkb * b1[k];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       Z[0][e] = z[2 * e];
@@ -151,12 +177,22 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
     bsum[fa] += (Z[1][0] + Z[1][1]) + (Z[1][2] + Z[1][3]);
   };
   // V[c][e] for 32 ci: patch rows 2g + i1, 2g + i2, columns 8*half .. 8*half + 9
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
   auto prep_v = [&](int buf, const int g, const int fb, f32x4 (&V)[4]) {
-    const float* xa = xbase + buf + (2 * g + i1) * XW * LDX + fb * 32;
-    const float* xb = xbase + buf + (2 * g + i2) * XW * LDX + fb * 32;
+    const float* xa = xbase + buf + ((2 * g + i1) * CG + fb * 32) * WP;
+    const float* xb = xbase + buf + ((2 * g + i2) * CG + fb * 32) * WP;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa), a1 = *reinterpret_cast<const f32x4*>(xa + 4);
+    const f32x2_ a2 = *reinterpret_cast<const f32x2_*>(xa + 8);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(xb), b1 = *reinterpret_cast<const f32x4*>(xb + 4);
+    const f32x2_ b2 = *reinterpret_cast<const f32x2_*>(xb + 8);
     float R[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) R[k] = xa[k * LDX] + s2 * xb[k * LDX];
+    for (int k = 0; k < 4; ++k) {
+      R[k] = a0[k] + s2 * b0[k];
+      R[4 + k] = a1[k] + s2 * b1[k];
+    }
+    R[8] = a2[0] + s2 * b2[0];
+    R[9] = a2[1] + s2 * b2[1];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       V[0][e] = R[2 * e] - R[2 * e + 2];
