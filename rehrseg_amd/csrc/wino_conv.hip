@@ -883,7 +883,8 @@ bool three_taps(const rehr_axis_taps& t, int b) {
 }
 
 bool w32_ok(const rehr_gather_gemm_desc& d) {
-  if (d.Npad % 64 == 0 || d.Lh < 32 || d.Lw < 16) return false;
+  static const bool force = getenv("REHR_WINO_W32") != nullptr;  // A/B switch for benchmarking
+  if ((d.Npad % 64 == 0 && !force) || d.Lh < 32 || d.Lw < 16) return false;
   const int64_t nb_h = (d.Lh + 31) / 32, nb_w = (d.Lw + 15) / 16;
   return nb_h * 32 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13;
 }
