@@ -230,11 +230,13 @@ def main():
             wc["executed_frac"] = wc["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS
             rec["roofline"] = wc
         for name, key in (("gather_gemm", "roofline_gather_gemm"), ("wino_wgrad", "roofline_wino_wgrad"),
+                          ("wino22_conv", "roofline_wino22_conv"), ("wino22_wgrad", "roofline_wino22_wgrad"),
                           ("wgrad", "roofline_wgrad")):
             f = fam(name)
             if f:
-                if name == "wino_wgrad":
-                    f["executed_tflops"] = f["achieved"] * 16.0 / 36.0
+                if name.startswith("wino"):  # F(2x2,3x3): 16 of 36 products; F(2x2,2x2): 9 of 16
+                    k = 16.0 / 36.0 if name == "wino_wgrad" else 9.0 / 16.0
+                    f["executed_tflops"] = f["achieved"] * k
                     f["executed_frac"] = f["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS
                 if not wc and name == "gather_gemm":
                     f["traffic"] = None

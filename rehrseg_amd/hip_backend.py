@@ -159,10 +159,17 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
 
 
+def _gg_family(d):
+    """Profiling family of a launch: which kernel family the library picks for this descriptor."""
+    if not d.wino_ws:
+        return "gather_gemm"
+    return "wino_conv" if d.th.count == 3 else "wino22_conv"
+
+
 def gather_gemm(*args):
     d = L.GatherGemmDesc()
     flops = _gg_desc(d, *args)
-    with _timed("wino_conv" if d.wino_ws else "gather_gemm", flops):
+    with _timed(_gg_family(d), flops):
         L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
 
 
@@ -172,7 +179,7 @@ def gather_gemm_multi(calls):
         return gather_gemm(*calls[0])
     arr = (L.GatherGemmDesc * len(calls))()
     flops = sum(_gg_desc(arr[i], *a) for i, a in enumerate(calls))
-    with _timed("gather_gemm", flops):
+    with _timed(_gg_family(arr[0]) if all(arr[i].wino_ws for i in range(len(calls))) else "gather_gemm", flops):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 
 
@@ -219,7 +226,7 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
     d.workspace, d.workspace_bytes = _ptr(ws), nbytes
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
-    with _timed("wino_wgrad" if wino else "wgrad", flops):
+    with _timed(("wino_wgrad" if d.th.count == 3 else "wino22_wgrad") if wino else "wgrad", flops):
         L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
 
 
