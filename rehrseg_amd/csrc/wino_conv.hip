@@ -385,11 +385,15 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   constexpr int NXA = 6;  // pieces fetched / staged in the first half (the rest in the second)
   f32x4 rx[NXA];
   const int items = (p.dbg & 2) ? 0 : p.kchunks * d.td.count;
-  auto fetch_to = [&](f32x4 (&rx)[NXA], int it, const int lo, const int hi) {
-    const bool live = it < items;
-    const int ii = live ? it : 0;
-    const int jd = ii % d.td.count;
-    const int cc = (ii / d.td.count) * 32;
+  // items are walked with (chunk, depth tap) counters: no integer division inside the loop
+  struct Item { int chunk, jd; };
+  auto advance = [&](Item& t) {
+    if (++t.jd == d.td.count) { t.jd = 0; ++t.chunk; }
+  };
+  auto fetch_to = [&](f32x4 (&rx)[NXA], const Item& t, const int lo, const int hi) {
+    const bool live = (t.chunk < p.kchunks) & (items > 0);
+    const int jd = t.jd;
+    const int cc = (live ? t.chunk : 0) * 32;
     const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
     const bool first = cc < d.c1;
     const float* src = first ? d.x1 : d.x2;
@@ -415,24 +419,25 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
       if (piece < PVOX2 * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LDX + row * 8 + pq * 4) = rx[i - lo];
     }
   };
-  auto fetch = [&](int it, const int lo, const int hi) { fetch_to(rx, it, lo, hi); };
+  auto fetch = [&](const Item& t, const int lo, const int hi) { fetch_to(rx, t, lo, hi); };
   auto stage = [&](int buf, const int lo, const int hi) { stage_from(rx, buf, lo, hi); };
 
   const __amdgpu_buffer_rsrc_t rsu =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
   const int NT = d.Npad / 32;
   const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
-  auto load_u = [&](int it, int kk, f32x4 (&ub)[2][4]) {
-    const int jd = it % d.td.count;
-    const int chunk = it / d.td.count;
-    const uint32_t base = (uint32_t)(jd * 16 + r * 4) * xi_stride + (uint32_t)nt0 * nt_stride +
-                          (uint32_t)(chunk * 4 + kk) * 1024u + (uint32_t)lane * 16u;
+  // the fragment address is wave-uniform except for the lane's 16 bytes: scalar offset operand, no VALU
+  const uint32_t ulane = (uint32_t)lane * 16u;
+  const uint32_t ubase = (uint32_t)(r * 4) * xi_stride + (uint32_t)nt0 * nt_stride;
+  auto load_u = [&](const Item& t, int kk, f32x4 (&ub)[2][4]) {
+    const int chunk = t.chunk < p.kchunks ? t.chunk : 0;  // (one item past the end is requested, never used)
+    const uint32_t base = ubase + (uint32_t)(t.jd * 16) * xi_stride + (uint32_t)(chunk * 4 + kk) * 1024u;
 #pragma unroll
     for (int fn = 0; fn < 2; ++fn)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         ub[fn][c] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride + fn * nt_stride, 0, 0));
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, base + c * xi_stride + fn * nt_stride, 0));
   };
 
   f32x16 acc[2][2][4];
@@ -499,11 +504,12 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
 
   VFrag VA, VB;
   f32x4 u0[2][4], u1[2][4];
+  Item ci = {0, 0}, ni = {0, 0};
   {  // item 0: all 11 pieces in flight at once (u1's registers are free here)
-    fetch(0, 0, NXA);
+    fetch(ci, 0, NXA);
     f32x4 (&rx2)[NXA] = reinterpret_cast<f32x4 (&)[NXA]>(u1);
-    fetch_to(rx2, 0, NXA, NX2);
-    load_u(0, 0, u0);
+    fetch_to(rx2, ci, NXA, NX2);
+    load_u(ci, 0, u0);
     stage(0, 0, NXA);
     stage_from(rx2, 0, NXA, NX2);
   }
@@ -513,18 +519,19 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
 
   for (int it = 0; it < items; ++it) {
     const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
-    const int itn = it + 1 < items ? it + 1 : it;
-    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 0, 1), load_u(it, 1, u1), fetch(it + 1, 0, NXA)))
+    advance(ni);
+    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 0, 1), load_u(ci, 1, u1), fetch(ni, 0, NXA)))
     WINO_MICRO(1, VB, VA, u0, issue_reads(cur, 1, 0))
     WINO_MICRO(0, VA, VB, u1,
-               (issue_reads(cur, 1, 1), load_u(it, 2, u0), stage(nxt, 0, NXA), fetch(it + 1, NXA, NX2)))
+               (issue_reads(cur, 1, 1), load_u(ci, 2, u0), stage(nxt, 0, NXA), fetch(ni, NXA, NX2)))
     WINO_MICRO(1, VB, VA, u1, issue_reads(cur, 2, 0))
-    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 2, 1), load_u(it, 3, u1), stage(nxt, NXA, NX2)))
+    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 2, 1), load_u(ci, 3, u1), stage(nxt, NXA, NX2)))
     WINO_MICRO(1, VB, VA, u0, issue_reads(cur, 3, 0))
-    WINO_MICRO(0, VA, VB, u1, (issue_reads(cur, 3, 1), load_u(itn, 0, u0)))
+    WINO_MICRO(0, VA, VB, u1, (issue_reads(cur, 3, 1), load_u(ni, 0, u0)))
     // every read of slice `cur` has been consumed, every write of `nxt` was issued long ago
     __syncthreads();
     WINO_MICRO(1, VB, VA, u1, issue_reads(nxt, 0, 0))
+    ci = ni;
   }
 #undef WINO_MICRO
   __syncthreads();
