@@ -300,7 +300,8 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
 }
 
 bool plan22(const rehr_gather_gemm_desc& d, W22Params& p) {
-  static const bool off = getenv("REHR_WINO22") && getenv("REHR_WINO22")[0] == '0';
+  const char* env22 = getenv("REHR_WINO22");  // read per call: tests switch the path at run time
+  const bool off = env22 && env22[0] == '0';
   if (off) return false;
   if (d.sd != 1) return false;
   AxisPlan ah, aw;

@@ -379,7 +379,8 @@ bool three_taps_w(const rehr_axis_taps& t, int b) {
 }
 
 bool plan(const rehr_wgrad_desc& d, WWParams& p) {
-  static const bool off = getenv("REHR_WINO_WGRAD") && getenv("REHR_WINO_WGRAD")[0] == '0';
+  const char* envw = getenv("REHR_WINO_WGRAD");  // read per call: tests switch the path at run time
+  const bool off = envw && envw[0] == '0';
   if (off) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (!three_taps_w(d.th, d.bh) || !three_taps_w(d.tw, d.bw)) return false;

@@ -1,0 +1,179 @@
+"""BASELINE.json's full sizes (cfg-2: FLAVR 1x1x128^3, cfg-3: SegModel 2x1x128^3) are beyond what the CPU oracle
+finishes in seconds, so they are checked through size-independent properties on the MI355X:
+
+  * two independent implementations agree: the transform-domain (Winograd) kernels against the direct
+    gather-GEMM / slab kernels (each pinned against the reference at small sizes).  Loss to 1e-5; every
+    parameter gradient to within 3x of what the DIRECT kernels themselves move when the input is perturbed at
+    fp32 rounding level (x * (1 + 1e-7 * N(0,1))).  At random initialisation the deep gradients of this
+    50-layer network are that ill-conditioned (up to 2e-3 relative for layer3/4 -- measured, see DESIGN.md
+    section 5), so a fixed 1e-3 bound would be testing the conditioning of the problem, not the kernels;
+    the weight-gradient kernels in isolation agree to 2e-6;
+  * the backward pass is the derivative of the forward pass where fp32 loss values can resolve it (the
+    parameters of the last layers): central difference along the gradient direction, 2 %;
+  * re-running the step reproduces the gradients to 1e-5 relative (split-K slabs are reduced in a fixed order;
+    the only atomics are the fp64 SE / InstanceNorm statistics, whose summation order moves the last bits of
+    the fp32 gate values);
+  * FLAVR rewrites channel 0 of its input in place exactly like the reference (mean subtraction).
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class direct_kernels:
+    """Run with every Winograd path switched off (forward/dgrad via the scratch switch, wgrad via the
+    library's per-call environment switches)."""
+
+    def __enter__(self):
+        from rehrseg_amd import hip_backend
+        self.hb, self.prev = hip_backend, hip_backend.USE_WINOGRAD
+        hip_backend.USE_WINOGRAD = False
+        os.environ["REHR_WINO_WGRAD"] = "0"
+        os.environ["REHR_WINO22"] = "0"
+
+    def __exit__(self, *a):
+        self.hb.USE_WINOGRAD = self.prev
+        os.environ.pop("REHR_WINO_WGRAD")
+        os.environ.pop("REHR_WINO22")
+
+
+def _grads(model, loss_fn):
+    for p in model.parameters():
+        p.grad = None
+    loss = loss_fn()
+    loss.backward()
+    return float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _compare(ga, gb, tol):
+    worst = (0.0, None)
+    for n in gb:
+        scale = float(gb[n].abs().max())
+        if scale == 0.0:
+            continue
+        err = float((ga[n] - gb[n]).abs().max()) / scale
+        if err > worst[0]:
+            worst = (err, n)
+    assert worst[0] <= tol, worst
+    return worst
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _compare_to_conditioning(g_test, g_ref, g_perturbed, factor=3.0, floor=1e-5):
+    """|g_test - g_ref| <= factor * |g_perturbed - g_ref| + floor * |g_ref| for every parameter (l2)."""
+    worst = (0.0, None, 0.0)
+    for n in g_ref:
+        d, s = _rel(g_test[n], g_ref[n]), _rel(g_perturbed[n], g_ref[n])
+        assert d <= factor * s + floor, (n, d, s)
+        if d > worst[0]:
+            worst = (d, n, s)
+    return worst
+
+
+def _fd_check(loss_fn, p, grad, rel=0.02):
+    d = grad / (grad.abs().mean() + 1e-20) * (float(p.detach().abs().mean()) + 1e-3)
+    analytic = float((grad.double() * d.double()).sum())
+    eps = 2e-4   # loss change ~4e-5: three digits above the fp32 resolution of the loss, third-order term negligible
+    with torch.no_grad():
+        p.add_(d, alpha=eps)
+        lp = float(loss_fn())
+        p.add_(d, alpha=-2 * eps)
+        lm = float(loss_fn())
+        p.add_(d, alpha=eps)
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(numeric - analytic) <= rel * abs(analytic), (numeric, analytic)
+
+
+def test_cfg2_flavr_128cube_properties():
+    from rehrseg_amd import hip_backend
+    from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = UNet_3D_3D(1, "unet_18", 128, 4).to(dev)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(1, 1, 128, 128, 128, generator=g).to(dev)
+    tgt = torch.rand(1, 1, 4, 128, 128, generator=g).to(dev)
+
+    def loss_fn():
+        return ((model(x.clone()) - tgt) ** 2).mean()
+
+    before = (hip_backend.wino_launches, hip_backend.wino_wgrad_launches)
+    la, ga = _grads(model, loss_fn)
+    used = (hip_backend.wino_launches - before[0], hip_backend.wino_wgrad_launches - before[1])
+    assert used[0] >= 40 and used[1] >= 20, used          # the step really ran on the Winograd kernels
+    lr, gr = _grads(model, loss_fn)
+    assert abs(la - lr) <= 1e-6 * abs(la)
+    _compare(gr, ga, 1e-5)
+    xs = [x]
+
+    def loss_px():
+        return ((model(xs[0].clone()) - tgt) ** 2).mean()
+
+    with direct_kernels():
+        before = hip_backend.wino_launches
+        lb, gb = _grads(model, loss_fn)
+        assert hip_backend.wino_launches == before
+        xs[0] = x * (1 + 1e-7 * torch.randn(x.shape, generator=g).to(dev))
+        _, gp = _grads(model, loss_px)
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    print("winograd vs direct kernels (worst l2-rel, parameter, direct kernels' own sensitivity):",
+          _compare_to_conditioning(ga, gb, gp))
+    # the weight-gradient kernels alone (same dY, same x): direct forward/dgrad, Winograd wgrad
+    hip_backend.USE_WINOGRAD = False
+    try:
+        _, gw = _grads(model, loss_fn)
+    finally:
+        hip_backend.USE_WINOGRAD = True
+    for n in gb:
+        assert _rel(gw[n], gb[n]) <= 2e-5, (n, _rel(gw[n], gb[n]))
+    pd = dict(model.named_parameters())
+    for n in ("outconv.1.weight", "feature_fuse.conv.0.weight"):
+        _fd_check(loss_fn, pd[n], ga[n])
+    xin = x.clone()
+    model(xin)
+    assert torch.allclose(xin[:, 0:1], x[:, 0:1] - x[:, 0:1].mean((2, 3, 4), keepdim=True), atol=1e-6)
+
+
+def test_cfg3_segmodel_128cube_properties():
+    from oracle import segmodel_oracle as so
+    from rehrseg_amd import hip_backend
+    from rehrseg_amd.utils.seg_utils import _build_loss
+    from test_segmodel_cpu import build
+    dev = torch.device("cuda:0")
+    model = build(so.ISO_PLAN, dev)[0]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 1, 128, 128, 128, generator=g).to(dev)
+    lab_lr = torch.randint(0, 2, (2, 1, 128, 128, 128), generator=g).float().to(dev)
+    lab_hr = torch.randint(0, 2, (2, 1, 512, 128, 128), generator=g).float().to(dev)
+    crit = _build_loss()
+
+    def loss_fn():
+        out, out_up = model(x)
+        return crit(out, lab_lr) + crit(out_up, lab_hr)
+
+    before = hip_backend.wino_launches
+    la, ga = _grads(model, loss_fn)
+    assert hip_backend.wino_launches - before >= 30
+    xs = [x]
+
+    def loss_px():
+        out, out_up = model(xs[0])
+        return crit(out, lab_lr) + crit(out_up, lab_hr)
+
+    with direct_kernels():
+        lb, gb = _grads(model, loss_fn)
+        xs[0] = x * (1 + 1e-7 * torch.randn(x.shape, generator=g).to(dev))
+        _, gp = _grads(model, loss_px)
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    # InstanceNorm stacks amplify fp32 rounding even more (tests/test_segmodel_cpu.py: torch's own fp32 CPU
+    # gradients sit ~4e-3 from an fp64 run on this plan): same conditioning-relative criterion
+    print("winograd vs direct kernels (worst l2-rel, parameter, direct kernels' own sensitivity):",
+          _compare_to_conditioning(ga, gb, gp))
+    pd = dict(model.named_parameters())
+    _fd_check(loss_fn, pd["sr_head.2.weight"], ga["sr_head.2.weight"], rel=0.02)
