@@ -314,7 +314,25 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
     return out[0], out[1]
 
 
-def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias):
+# Parameters whose .grad is a view into a caller-owned flat buffer (rehrseg_amd.parallel.PatchParallel):
+# weight.data_ptr() -> (parameter, owner).  The weight-gradient kernels then write straight into that view
+# and the owner is told the gradient is ready, instead of returning a temporary for autograd to add into it
+# (one extra elementwise pass and one allocation per parameter and step).
+_direct_grad = {}
+
+
+def _direct_grad_target(w):
+    ent = _direct_grad.get(w.data_ptr())
+    if ent is None:
+        return None
+    param, owner = ent
+    g = param.grad
+    if g is None or g.shape != w.shape or not g.is_contiguous() or owner.was_written(param):
+        return None
+    return param, owner, g
+
+
+def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
     """(dw, db) in the torch parameter layout of ``w``."""
     be = get_backend()
     N = x1.shape[0]
@@ -337,7 +355,7 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias):
         return tmp[:, :kcols].reshape(w.shape).contiguous(), db
     if _thin_out(w, cfg, x2 is not None):
         return be.small_cout_wgrad(x1, w, dz, cfg.pad, want_bias)
-    dw = torch.empty(tuple(w.shape), dtype=w.dtype, device=w.device)
+    dw = out if out is not None else torch.empty(tuple(w.shape), dtype=w.dtype, device=w.device)
     db = None
     taps = [full_taps(k) for k in K]
     b = tuple(-p for p in cfg.pad)
@@ -430,7 +448,15 @@ class _FusedConv(torch.autograd.Function):
             dx1, dx2 = conv_dgrad(dz, w, _spatial(x1), c1, c2, cfg, need[0], has_x2 and need[1])
         dw = db = None
         if need[2] or (has_b and need[3]):
-            dw, db = conv_wgrad(dz, x1, x2, w, cfg, has_b)
+            c1_ = x1.shape[1] + (x2.shape[1] if has_x2 else 0)
+            generic = c1_ > 2 and not _thin_out(w, cfg, has_x2)       # the paths that fill a caller-given tensor
+            tgt = _direct_grad_target(w) if (need[2] and generic) else None
+            if tgt is not None:
+                param, owner, gview = tgt
+                _, db = conv_wgrad(dz, x1, x2, w, cfg, has_b, out=gview)
+                owner.grad_written(param)
+            else:
+                dw, db = conv_wgrad(dz, x1, x2, w, cfg, has_b)
         return dx1, dx2, dw, db, dp1, dp2, dres, None
 
 

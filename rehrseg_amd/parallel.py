@@ -44,6 +44,12 @@ class PatchParallel:
             b[2] += 1
             self._bucket_of[p] = len(self.buckets) - 1
             off += n
+        # conv weights: let the weight-gradient kernels write into the flat buffer directly (rehrseg_amd.ops)
+        from . import ops
+        self._written = set()
+        for p in self.params:
+            if p.dim() == 5 and p.is_cuda:
+                ops._direct_grad[p.data_ptr()] = (p, self)
         self.overlap = overlap and self.world > 1
         self._pending = [b[2] for b in self.buckets]
         self._works = []
@@ -69,9 +75,20 @@ class PatchParallel:
         if self._pending[i] == 0 and not self._launched[i]:
             self._launch(i)
 
+    # ---- direct gradient writes (see rehrseg_amd.ops._direct_grad)
+    def was_written(self, p):
+        return id(p) in self._written
+
+    def grad_written(self, p):
+        """A kernel has overwritten p.grad in place for this step: same bookkeeping as the autograd hook."""
+        self._written.add(id(p))
+        if self.overlap:
+            self._on_grad_ready(p)
+
     def zero_grad(self):
         """Keeps the .grad views (optimizer.zero_grad(set_to_none=True) would drop them)."""
         self.flat.zero_()
+        self._written.clear()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
