@@ -639,25 +639,28 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
 
 // ------------------------------------------------------------------------------------------
 // Wide-tile variant for 32-wide output-channel tiles (nnU-Net stage-0 / last decoder stage, SR
-// head): 128 Winograd tiles (32 x 16 outputs of one depth slice) x 32 channels per block.  Same
-// organisation as the big-tile kernel (one block per CU, wave r = Winograd row r, 16 accumulator
-// tiles in AGPRs = 4 tile groups x 4 columns); every weight fragment now feeds FOUR tile groups,
-// so the small-tile kernel's weight traffic per MFMA (its limiter: 2 blocks/CU, each fragment used
-// once) drops 4x.  K items are 16-channel half chunks so that the 34 x 18 patch double-buffers in
+// head): 128 Winograd tiles (32 x 16 outputs of one depth slice) x 32 channels per block, one block
+// of 16 waves per CU (wave = Winograd row x tile group, 4 accumulator tiles each).  The four tile
+// groups share every weight fragment through L1/L2, so the small-tile kernel's weight traffic per
+// MFMA from L2 (its limiter: 2 blocks/CU on different tiles) drops.  K items are 16-channel half chunks so that the 34 x 18 patch double-buffers in
 // LDS (row pitch 368 floats, even/odd column split: conflict-free fragment reads).
 constexpr int W3_ROWS = 34, W3_LD = 20, W3_RP = PW2 * W3_LD + 8, W3_BUF = W3_ROWS * W3_RP;
 constexpr int W3_VOX = W3_ROWS * PW2;                 // 612 patch voxels
 constexpr int W3_NX = (W3_VOX * 4 + 255) / 256;       // 10 16-byte pieces per thread
 constexpr int W3_FMOFF = 8 * W3_RP;                   // next tile group = 4 tile rows = 8 patch rows
 
-__global__ __launch_bounds__(256) void wino_conv_w32_kernel(const WinoParams p) {
+__global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p) {
   const rehr_gather_gemm_desc& d = p.d;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;  // [2][W3_BUF]; reused as the exchange buffer at the end
   constexpr int BUF = W3_BUF;
 
+  // 16 waves = 4 Winograd rows x 4 tile groups, four per SIMD: with one channel group there is no
+  // input-fragment reuse to organise in registers, so thread-level parallelism hides the latencies
+  // instead of a hand-built pipeline (the 4-wave version of this kernel issued 47 % of the MFMA peak)
   const int tid = threadIdx.x, lane = tid & 63;
-  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = wv & 3, fm = wv >> 2;
   const int half = lane >> 5, col = lane & 31;
   const int n_img = blockIdx.z;
   const int nt0 = blockIdx.y, n0 = blockIdx.y * 32;
@@ -670,16 +673,17 @@ __global__ __launch_bounds__(256) void wino_conv_w32_kernel(const WinoParams p) 
   const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
   const float s2 = (r == 1) ? 1.f : -1.f;
   const float rsign = (r == 2) ? -1.f : 1.f;
-  const int th_ = col >> 3, tw_ = col & 7;  // tile of group 0; group fm = 4*fm tile rows further
+  const int th_ = fm * 4 + (col >> 3), tw_ = col & 7;
   const float* xa = Xs + (2 * th_ + i1) * W3_RP + tw_ * W3_LD + 4 * half;
   const float* xb = Xs + (2 * th_ + i2) * W3_RP + tw_ * W3_LD + 4 * half;
 
-  // staging pieces (LDS order: 4 pieces = 16 channels per voxel slot)
-  int pvx[W3_NX];
+  // staging pieces (LDS order: 4 pieces = 16 channels per voxel slot), 3 per thread
+  constexpr int NXT = (W3_VOX * 4 + 1023) / 1024;
+  int pvx[NXT];
   uint32_t pok = 0;
 #pragma unroll
-  for (int i = 0; i < W3_NX; ++i) {
-    const int piece = tid + 256 * i;
+  for (int i = 0; i < NXT; ++i) {
+    const int piece = tid + 1024 * i;
     const int v = piece >> 2;
     const int ph = v / PW2, slot = v - ph * PW2;
     const int pw_ = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
@@ -692,12 +696,15 @@ __global__ __launch_bounds__(256) void wino_conv_w32_kernel(const WinoParams p) 
   const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
   const int nhalf = (d.Cin + 15) / 16;
   const int items = nhalf * d.td.count;  // (16-channel half chunk, depth tap)
-  f32x4 rx[W3_NX];
-  auto fetch = [&](int it) {
-    const bool live = it < items;
-    const int ii = live ? it : 0;
-    const int jd = ii % d.td.count;
-    const int cc = (ii / d.td.count) * 16;
+  struct Item { int h16, jd; };
+  auto advance = [&](Item& t) {
+    if (++t.jd == d.td.count) { t.jd = 0; ++t.h16; }
+  };
+  f32x4 rx[NXT];
+  auto fetch = [&](const Item& t) {
+    const bool live = t.h16 < nhalf;
+    const int jd = t.jd;
+    const int cc = (live ? t.h16 : 0) * 16;
     const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
     const bool first = cc < d.c1;
     const float* src = first ? d.x1 : d.x2;
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(256) void wino_conv_w32_kernel(const WinoParams p) 
     const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
     const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
 #pragma unroll
-    for (int i = 0; i < W3_NX; ++i) {
+    for (int i = 0; i < NXT; ++i) {
       const bool ok = dok & ((pok >> i) & 1u);
       const uint32_t off = base + (uint32_t)pvx[i] * ld * 4u;
       rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
@@ -717,100 +724,77 @@ __global__ __launch_bounds__(256) void wino_conv_w32_kernel(const WinoParams p) 
   };
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < W3_NX; ++i) {
-      const int piece = tid + 256 * i;
+    for (int i = 0; i < NXT; ++i) {
+      const int piece = tid + 1024 * i;
       const int v = piece >> 2, row = (v * 3641) >> 16;  // v / 18 for v < 1024
       if (piece < W3_VOX * 4) *reinterpret_cast<f32x4*>(Xs + buf + v * W3_LD + row * 8 + pq * 4) = rx[i];
     }
   };
 
-  // weight fragments (fragment-ordered panel [jd][xi][Npad/32][kchunks32][kk 4][lane][4])
+  // weight fragments (fragment-ordered panel [jd][xi][Npad/32][kchunks32][kk 4][lane][4]): scalar offsets
   const __amdgpu_buffer_rsrc_t rsu =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
   const int NT = d.Npad / 32;
   const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
-  auto load_u = [&](int it, const int kkl, f32x4 (&ub)[4]) {
-    const int jd = it % d.td.count;
-    const int h16 = it / d.td.count;
-    const uint32_t base = (uint32_t)(jd * 16 + r * 4) * xi_stride + (uint32_t)nt0 * nt_stride +
-                          (uint32_t)((h16 >> 1) * 4 + (h16 & 1) * 2 + kkl) * 1024u + (uint32_t)lane * 16u;
+  const uint32_t ulane = (uint32_t)lane * 16u, ubase = (uint32_t)(r * 4) * xi_stride + (uint32_t)nt0 * nt_stride;
+  auto load_u = [&](const Item& t, const int kkl, f32x4 (&ub)[4]) {
+    const int h16 = t.h16 < nhalf ? t.h16 : 0;  // (one item past the end is requested, never used)
+    const uint32_t base = ubase + (uint32_t)(t.jd * 16) * xi_stride +
+                          (uint32_t)((h16 >> 1) * 4 + (h16 & 1) * 2 + kkl) * 1024u;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride, 0, 0));
+      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, base + c * xi_stride, 0));
   };
 
-  f32x16 acc[4][4];
+  f32x16 acc[4];
 #pragma unroll
-  for (int fm = 0; fm < 4; ++fm)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[fm][c][q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
 
-  f32x4 ra[4], rb[4];
-  auto issue_reads = [&](int buf, const int kkl, const int fm) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * W3_FMOFF + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8);
-      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + fm * W3_FMOFF + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8);
-    }
-  };
-  auto combine = [&](f32x4 (&v)[4]) {
+  auto kstep = [&](int buf, const int kkl, const f32x4 (&ub)[4]) {
     f32x4 R[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) R[j] = ra[j] + rb[j] * s2;
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8);
+      R[j] = a + bq * s2;
+    }
+    f32x4 v[4];
     v[0] = R[0] - R[2];
     v[1] = R[1] + R[2];
     v[2] = R[1] - R[2];  // negated column, undone at the output
     v[3] = R[1] - R[3];
-  };
-  auto mfmas = [&](const int fm, const f32x4 (&v)[4], const f32x4 (&ub)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        acc[fm][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[fm][c], 0, 0, 0);
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
   };
-// micro-step = (k-group, tile group) = 16 MFMAs; the next micro-step's fragments are read and combined
-// underneath; the compiler interleaves inside the region
-#define W32_MICRO(fm, vcur, vnext, u, ISSUE) \
-  __builtin_amdgcn_sched_barrier(0);         \
-  ISSUE;                                     \
-  mfmas(fm, vcur, u);                        \
-  combine(vnext);                            \
-  __builtin_amdgcn_sched_barrier(0);
 
-  f32x4 VA[4], VB[4], u0[4], u1[4];
-  fetch(0);
-  load_u(0, 0, u0);
+  f32x4 u0[4], u1[4];
+  Item ci = {0, 0}, ni = {0, 0};
+  fetch(ci);
+  load_u(ci, 0, u0);
   stage(0);
   __syncthreads();
-  issue_reads(0, 0, 0);
-  combine(VA);
-
   for (int it = 0; it < items; ++it) {
     const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
-    const int itn = it + 1 < items ? it + 1 : it;
-    W32_MICRO(0, VA, VB, u0, (issue_reads(cur, 0, 1), load_u(it, 1, u1), fetch(it + 1)))
-    W32_MICRO(1, VB, VA, u0, issue_reads(cur, 0, 2))
-    W32_MICRO(2, VA, VB, u0, issue_reads(cur, 0, 3))
-    W32_MICRO(3, VB, VA, u0, issue_reads(cur, 1, 0))
-    W32_MICRO(0, VA, VB, u1, (issue_reads(cur, 1, 1), load_u(itn, 0, u0)))
-    W32_MICRO(1, VB, VA, u1, (issue_reads(cur, 1, 2), stage(nxt)))
-    W32_MICRO(2, VA, VB, u1, issue_reads(cur, 1, 3))
-    // every read of slice `cur` has been consumed; the writes of `nxt` were issued a micro-step ago
+    advance(ni);
+    fetch(ni);
+    load_u(ci, 1, u1);
+    kstep(cur, 0, u0);
+    load_u(ni, 0, u0);
+    kstep(cur, 1, u1);
+    stage(nxt);
+    ci = ni;
     __syncthreads();
-    W32_MICRO(3, VB, VA, u1, issue_reads(nxt, 0, 0))
   }
-#undef W32_MICRO
-  __syncthreads();
 
-  // ---- output transform: columns in registers, rows across the 4 waves through LDS
+  // ---- output transform: columns in registers, rows across the 4 row-waves of a tile group through LDS
   float* ex = smem;  // [fm][r][c'][q][lane]
-#pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
-    const f32x16 T0 = (acc[fm][0] + acc[fm][1] - acc[fm][2]) * rsign;
-    const f32x16 T1 = (acc[fm][1] + acc[fm][2] - acc[fm][3]) * rsign;
+  {
+    const f32x16 T0 = (acc[0] + acc[1] - acc[2]) * rsign;
+    const f32x16 T1 = (acc[1] + acc[2] - acc[3]) * rsign;
     float* e0 = ex + ((fm * 4 + r) * 2) * 16 * 64 + lane;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -830,8 +814,7 @@ __global__ __launch_bounds__(256) void wino_conv_w32_kernel(const WinoParams p) 
   const bool colok = col_n < d.Cout;
   const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
   float s1_ = 0.f, s2_ = 0.f;
-#pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
+  {
     const float* e0 = ex + (fm * 4 * 2 + co) * 16 * 64 + lane;
     float t[4][16];
 #pragma unroll
@@ -867,15 +850,19 @@ __global__ __launch_bounds__(256) void wino_conv_w32_kernel(const WinoParams p) 
     s1_ += __shfl_xor(s1_, 32, 64);
     s2_ += __shfl_xor(s2_, 32, 64);
     __syncthreads();  // everybody is done reading ex
-    float* red = smem;
+    float* red = smem;  // [wave 16][2][32]
     if (half == 0) {
-      red[(r * 2 + 0) * 32 + col] = s1_;
-      red[(r * 2 + 1) * 32 + col] = s2_;
+      red[(wv * 2 + 0) * 32 + col] = s1_;
+      red[(wv * 2 + 1) * 32 + col] = s2_;
     }
     __syncthreads();
-    if (r == 0 && half == 0 && colok) {
-      const float a1 = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
-      const float a2 = red[32 + col] + red[96 + col] + red[160 + col] + red[224 + col];
+    if (wv == 0 && half == 0 && colok) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        a1 += red[(w * 2 + 0) * 32 + col];
+        a2 += red[(w * 2 + 1) * 32 + col];
+      }
       double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
       atomicAdd(st, (double)a1);
       if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
@@ -957,7 +944,7 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
       attr_set32 = true;
     }
     dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 32, d.N);
-    hipLaunchKernelGGL(wino_conv_w32_kernel, grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(wino_conv_w32_kernel, grid, dim3(1024), smem, stream, p);
     REHR_LAUNCH_CHECK();
     return REHR_OK;
   }
