@@ -179,7 +179,10 @@ class UNet_3D_3D(nn.Module):
                 out = out + torch.cat([img * sm[:, i:i + 1], out_multi[:, 2 * i + 1:2 * i + 2] * sm[:, i:i + 1]], 1)
             if return_inetermediate_uncertainty:
                 return imgs, uncs, segs
-            unc = torch.sigmoid(F.conv3d(sm, self.uncertainty_out.weight, self.uncertainty_out.bias))
+            # uncertainty_out is a 1x1x1 conv to ONE channel (ref :151,245): a weighted channel sum -- written as
+            # such, no vendor convolution library behind it (MIOpen picks its naive kernels for this shape)
+            wu = self.uncertainty_out.weight.view(1, -1, 1, 1, 1)
+            unc = torch.sigmoid((sm * wu).sum(1, keepdim=True) + self.uncertainty_out.bias.view(1, 1, 1, 1, 1))
             return out, unc
 
         out = self._outconv(fused)
