@@ -124,14 +124,18 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   }
   const int pq = tid & 7;
   const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
-  const int per_phase = p.kchunks * d.td.count;
-  const int items = p.nphase * per_phase;
+  int jd_lo = d.td.count, jd_hi = -1;  // depth taps with a source slice inside the volume (block-uniform)
+  for (int j = 0; j < d.td.count; ++j) {
+    const int id = od + d.bd + d.td.off0 + d.td.offs * j;
+    if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
+  }
+  const int items = p.nphase * p.kchunks * max(0, jd_hi - jd_lo + 1);
   f32x4 rx[NX];
   // items are walked with counters (phase, chunk, depth tap): no integer division in the loop
   struct Item { int ph, chunk, jd; };
   auto advance = [&](Item& t) {
-    if (++t.jd == d.td.count) {
-      t.jd = 0;
+    if (++t.jd > jd_hi) {
+      t.jd = jd_lo;
       if (++t.chunk == p.kchunks) { t.chunk = 0; ++t.ph; }
     }
   };
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   // item loop: weights one k-group ahead in registers, next item's patch fetched at the top and written to
   // the other LDS slice at the bottom; the three waves of a SIMD hide each other's LDS latency
   f32x4 u0[3], u1[3];
-  Item cur_i = {0, 0, 0}, nxt_i = {0, 0, 0};
+  Item cur_i = {0, 0, min(jd_lo, d.td.count - 1)}, nxt_i = cur_i;
   fetch(cur_i);
   load_u(cur_i, 0, u0);
   stage(0);

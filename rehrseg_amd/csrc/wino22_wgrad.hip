@@ -263,7 +263,7 @@ bool plan(const rehr_wgrad_desc& d, WW22Params& p) {
   p.sw = aw.stride;
   p.nb_h = (d.Lh + RH - 1) / RH;
   p.nb_w = (d.Lw + RW - 1) / RW;
-  if ((int64_t)p.nb_h * RH * p.nb_w * RW * 10 > (int64_t)d.Lh * d.Lw * 13) return false;
+  if ((int64_t)p.nb_h * RH * p.nb_w * RW * 100 > (int64_t)d.Lh * d.Lw * 134) return false;
   const int64_t items = (int64_t)d.N * d.Ld * p.nb_h * p.nb_w;
   if (items >= (1ll << 30) || items < 4) return false;
   p.items = (int)items;

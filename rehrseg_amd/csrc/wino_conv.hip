@@ -384,11 +384,18 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
   constexpr int NXA = 6;  // pieces fetched / staged in the first half (the rest in the second)
   f32x4 rx[NXA];
-  const int items = (p.dbg & 2) ? 0 : p.kchunks * d.td.count;
+  // depth taps whose source slice lies outside the volume contribute nothing for this whole block
+  // (od is block-uniform): walk only the valid range [jd_lo, jd_hi]
+  int jd_lo = d.td.count, jd_hi = -1;
+  for (int j = 0; j < d.td.count; ++j) {
+    const int id = od + d.bd + d.td.off0 + d.td.offs * j;
+    if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
+  }
+  const int items = (p.dbg & 2) ? 0 : p.kchunks * max(0, jd_hi - jd_lo + 1);
   // items are walked with (chunk, depth tap) counters: no integer division inside the loop
   struct Item { int chunk, jd; };
   auto advance = [&](Item& t) {
-    if (++t.jd == d.td.count) { t.jd = 0; ++t.chunk; }
+    if (++t.jd > jd_hi) { t.jd = jd_lo; ++t.chunk; }
   };
   auto fetch_to = [&](f32x4 (&rx)[NXA], const Item& t, const int lo, const int hi) {
     const bool live = (t.chunk < p.kchunks) & (items > 0);
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
 
   VFrag VA, VB;
   f32x4 u0[2][4], u1[2][4];
-  Item ci = {0, 0}, ni = {0, 0};
+  Item ci = {0, min(jd_lo, d.td.count - 1)}, ni = ci;
   {  // item 0: all 11 pieces in flight at once (u1's registers are free here)
     fetch(ci, 0, NXA);
     f32x4 (&rx2)[NXA] = reinterpret_cast<f32x4 (&)[NXA]>(u1);
@@ -695,10 +702,15 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
   const int pq = tid & 3;
   const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
   const int nhalf = (d.Cin + 15) / 16;
-  const int items = nhalf * d.td.count;  // (16-channel half chunk, depth tap)
+  int jd_lo = d.td.count, jd_hi = -1;  // depth taps with a source slice inside the volume (block-uniform)
+  for (int j = 0; j < d.td.count; ++j) {
+    const int id = od + d.bd + d.td.off0 + d.td.offs * j;
+    if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
+  }
+  const int items = nhalf * max(0, jd_hi - jd_lo + 1);  // (16-channel half chunk, valid depth tap)
   struct Item { int h16, jd; };
   auto advance = [&](Item& t) {
-    if (++t.jd == d.td.count) { t.jd = 0; ++t.h16; }
+    if (++t.jd > jd_hi) { t.jd = jd_lo; ++t.h16; }
   };
   f32x4 rx[NXT];
   auto fetch = [&](const Item& t) {
@@ -772,7 +784,7 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
   };
 
   f32x4 u0[4], u1[4];
-  Item ci = {0, 0}, ni = {0, 0};
+  Item ci = {0, min(jd_lo, d.td.count - 1)}, ni = ci;
   fetch(ci);
   load_u(ci, 0, u0);
   stage(0);
@@ -901,7 +913,7 @@ int64_t wino_workspace_bytes(const rehr_gather_gemm_desc& d) {
   if (d.Lh < 8 || d.Lw < 8) return 0;
   const bool big = big_ok(d) || w32_ok(d);
   const int64_t nb_h = (d.Lh + 2 * TH - 1) / (2 * TH), nb_w = (d.Lw + 2 * TW - 1) / (2 * TW);
-  if (!big && nb_h * 2 * TH * nb_w * 2 * TW * 10 > (int64_t)d.Lh * d.Lw * 13) return 0;
+  if (!big && nb_h * 2 * TH * nb_w * 2 * TW * 100 > (int64_t)d.Lh * d.Lw * 134) return 0;  // 24 x 24 (1.333) is in
   const int64_t cpad = (int64_t)((d.Cin + 31) / 32) * 32;  // the fragment-order layout pads Cin to 32
   const int64_t need = (int64_t)d.td.count * 16 * d.Npad * cpad * (int64_t)sizeof(float);
   if (need >= (1ll << 32) - 64) return 0;

@@ -201,7 +201,7 @@ def _tap_split(lattice, N, Npad, taps, Cin):
         # unit-stride 3x3 taps: leave lattices the Winograd kernels accept (8x16-output regions, <= 1.3x
         # padding; librehrseg's wino_workspace_bytes applies the same rule) to them
         Lh, Lw = lattice[1], lattice[2]
-        if Lh >= 8 and Lw >= 8 and (-(-Lh // 8) * 8) * (-(-Lw // 16) * 16) * 10 <= Lh * Lw * 13:
+        if Lh >= 8 and Lw >= 8 and (-(-Lh // 8) * 8) * (-(-Lw // 16) * 16) * 100 <= Lh * Lw * 134:
             return None
     want = min(8, max(2, 512 // blocks))
     kd, kh = taps[0][0], taps[1][0]
