@@ -470,6 +470,7 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
     if (descs[i].wino_ws != nullptr) {  // fewer multiplications beat better tiling: Winograd first
       int wrc = wino_conv_try(descs[i], st);
       if (wrc == REHR_ENOSUP) wrc = wino22_conv_try(descs[i], st);
+      if (wrc == REHR_ENOSUP) wrc = wino_flat_conv_try(descs[i], st);
       if (wrc == REHR_OK) continue;
       if (wrc != REHR_ENOSUP) return wrc;
     }
@@ -488,8 +489,10 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
 
 extern "C" int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* dp) {
   if (dp == nullptr || validate(*dp) != REHR_OK) return 0;
-  const int64_t b = wino_workspace_bytes(*dp);
-  return b > 0 ? b : wino22_workspace_bytes(*dp);
+  int64_t b = wino_workspace_bytes(*dp);
+  if (b == 0) b = wino22_workspace_bytes(*dp);
+  if (b == 0) b = wino_flat_workspace_bytes(*dp);
+  return b;
 }
 
 extern "C" int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* dp, void* stream) {

@@ -7,3 +7,7 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
 // F(2x2,2x2) variant for 2-tap phases / stride-2 4-tap gathers (wino22_conv.hip)
 int64_t wino22_workspace_bytes(const rehr_gather_gemm_desc& d);
 int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
+// small-lattice variant with flattened tile numbering (wino_flat_conv.hip)
+int wino_weights_frag_launch(const rehr_gather_gemm_desc& d, int kchunks, hipStream_t stream);
+int64_t wino_flat_workspace_bytes(const rehr_gather_gemm_desc& d);
+int wino_flat_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);

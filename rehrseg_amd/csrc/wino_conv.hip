@@ -30,7 +30,6 @@ struct WinoParams {
   rehr_gather_gemm_desc d;
   int nb_h, nb_w;       // 8 x 16 output regions per depth slice
   int kchunks;
-  int dbg;              // timing experiments only (REHR_WINO_DBG): 1 = no epilogue, 2 = no K loop
   int dh0, dw0;         // source offset of patch row/col 0 relative to the region origin (= -1 here)
   const float* up;      // U[jd][16][Npad][Cin]
   uint32_t up_bytes;
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
     const int id = od + d.bd + d.td.off0 + d.td.offs * j;
     if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
   }
-  const int items = (p.dbg & 2) ? 0 : p.kchunks * max(0, jd_hi - jd_lo + 1);
+  const int items = p.kchunks * max(0, jd_hi - jd_lo + 1);
   // items are walked with (chunk, depth tap) counters: no integer division inside the loop
   struct Item { int chunk, jd; };
   auto advance = [&](Item& t) {
@@ -542,7 +541,6 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   }
 #undef WINO_MICRO
   __syncthreads();
-  if (p.dbg & 1) return;
 
   // ---- output transform: columns in registers, rows across the 4 waves through LDS
   float* ex = smem;  // [fm*2+fn][r][c'][q][lane]
@@ -889,8 +887,7 @@ bool three_taps(const rehr_axis_taps& t, int b) {
 }
 
 bool w32_ok(const rehr_gather_gemm_desc& d) {
-  static const bool force = getenv("REHR_WINO_W32") != nullptr;  // A/B switch for benchmarking
-  if ((d.Npad % 64 == 0 && !force) || d.Lh < 32 || d.Lw < 16) return false;
+  if (d.Npad % 64 == 0 || d.Lh < 32 || d.Lw < 16) return false;  // 64-multiples: the big-tile kernel is faster
   const int64_t nb_h = (d.Lh + 31) / 32, nb_w = (d.Lw + 15) / 16;
   return nb_h * 32 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13;
 }
@@ -902,6 +899,16 @@ bool big_ok(const rehr_gather_gemm_desc& d) {
 }
 
 }  // namespace
+
+// fragment-ordered weight transform, shared with wino_flat_conv.hip
+int wino_weights_frag_launch(const rehr_gather_gemm_desc& d, int kchunks, hipStream_t stream) {
+  const int64_t total = (int64_t)d.td.count * d.Npad * kchunks * 32;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wino_weights_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, kchunks);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
 
 // scratch bytes when the descriptor suits one of the kernels, else 0
 int64_t wino_workspace_bytes(const rehr_gather_gemm_desc& d) {
@@ -936,8 +943,6 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   p.dw0 = -1;
   p.up = d.wino_ws;
   p.up_bytes = (uint32_t)need;
-  static const int dbg = getenv("REHR_WINO_DBG") ? atoi(getenv("REHR_WINO_DBG")) : 0;
-  p.dbg = dbg;
   if (w32_ok(d) && !no_big) {
     const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
     int64_t blocks = (total + 255) / 256;

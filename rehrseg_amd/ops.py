@@ -203,6 +203,11 @@ def _tap_split(lattice, N, Npad, taps, Cin):
         Lh, Lw = lattice[1], lattice[2]
         if Lh >= 8 and Lw >= 8 and (-(-Lh // 8) * 8) * (-(-Lw // 16) * 16) * 100 <= Lh * Lw * 134:
             return None
+        # ... and small planes the flattened-tile Winograd kernel takes (16..63 tiles per slice, >= 64 tiles)
+        tps = -(-Lh // 2) * -(-Lw // 2)
+        if (6 <= Lh <= 16 and 6 <= Lw <= 16 and 16 <= tps < 64 and Npad % 64 == 0 and
+                -(-(N * lattice[0] * tps) // 64) * (Npad // 64) >= 128):
+            return None
     want = min(8, max(2, 512 // blocks))
     kd, kh = taps[0][0], taps[1][0]
     nd = min(kd, want)

@@ -214,15 +214,17 @@ def test_split_k_many_depth_taps(emu):
 
 
 def test_split_k_low_resolution_stage(emu):
-    """<= 8^3-voxel stage: the taps are split over (depth, row) ranges for forward and input gradient, the
-    combine carries the InstanceNorm statistics."""
+    """4^3-voxel stage (too small even for the flattened-tile Winograd kernel): the taps are split over (depth, row)
+    ranges for forward and input gradient, the combine carries the InstanceNorm statistics."""
     assert ops._tap_split((4, 32, 32), 2, 64, [ops.full_taps(3)] * 3, 128) is None   # Winograd-sized lattice
-    parts = ops._tap_split((4, 8, 8), 2, 64, [ops.full_taps(3)] * 3, 128)
+    assert ops._tap_split((4, 12, 12), 32, 512, [ops.full_taps(3)] * 3, 512) is None  # flattened-tile Winograd
+    assert ops._tap_split((4, 8, 8), 2, 64, [ops.full_taps(3)] * 3, 128) is not None  # too few tiles for it
+    parts = ops._tap_split((4, 4, 4), 2, 64, [ops.full_taps(3)] * 3, 128)
     assert parts is not None and len(parts) == 6
     taps_seen = sorted((t[0][3] + i * t[0][4], t[1][3] + j * t[1][4]) for t in parts
                        for i in range(t[0][0]) for j in range(t[1][0]))
     assert taps_seen == sorted((i, j) for i in range(3) for j in range(3))   # every (kd, kh) exactly once
-    x = _rand(2, 128, 4, 8, 8).requires_grad_()
+    x = _rand(2, 128, 4, 4, 4).requires_grad_()
     w = _rand(64, 128, 3, 3, 3).requires_grad_()
     b, ga, be = _rand(64), _rand(64).requires_grad_(), _rand(64).requires_grad_()
     y = ops.fused_conv3d(x, w, b, 1, 1, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01)

@@ -98,6 +98,10 @@ WINO = [  # Cin, Cout, K, pad, dims, expected kernel launches through the Winogr
     (48, 32, (3, 3, 3), (1, 1, 1), (2, 2, 64, 32)),     # wide tile: 3 half chunks, 2 x 2 regions
     (32, 96, (3, 3, 3), (1, 1, 1), (1, 2, 60, 30)),     # wide tile: 3 channel tiles, ragged edges
     (64, 32, (1, 3, 3), (0, 1, 1), (1, 2, 32, 48)),     # wide tile, one depth tap
+    (128, 128, (3, 3, 3), (1, 1, 1), (32, 4, 12, 12)),  # small planes: flattened tiles, 36 per slice, 3 slices / block
+    (128, 128, (3, 3, 3), (1, 1, 1), (64, 4, 8, 8)),    # flattened tiles, 16 per slice (4 whole slices per block)
+    (128, 128, (3, 3, 3), (1, 1, 1), (42, 3, 14, 10)),  # flattened tiles, 35 per slice, last block partly empty
+    (48, 128, (1, 3, 3), (0, 1, 1), (120, 2, 12, 12)),  # flattened tiles, one depth tap, half last chunk
 ]
 
 
@@ -184,9 +188,10 @@ def test_split_k_many_depth_taps():
 
 
 def test_split_k_low_resolution_stage_with_instnorm():
-    """nnU-Net bottom stages (<= 8^3 voxels, hundreds of channels): 6 tap ranges in one grid, the combine
-    carries bias + InstanceNorm statistics; the input gradient takes the same route."""
-    x = _mk(2, 128, 4, 8, 8, seed=63)
+    """nnU-Net bottom stage (4^3 voxels, hundreds of channels): 6 tap ranges in one grid, the combine carries
+    bias + InstanceNorm statistics; the input gradient takes the same route.  (8^3 stages go to the
+    flattened-tile Winograd kernel.)"""
+    x = _mk(2, 128, 4, 4, 4, seed=63)
     w = _mk(192, 128, 3, 3, 3, seed=64) / (128 * 27) ** 0.5
     b, ga, be = _mk(192, seed=65), _mk(192, seed=66), _mk(192, seed=67)
     _run(lambda x, w, b, ga, be: ops.fused_conv3d(x, w, b, 1, 1, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
