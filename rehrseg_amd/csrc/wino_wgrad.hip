@@ -33,6 +33,11 @@ struct WWParams {
   int items, items_per_split, splits;
   int a_tiles, c_tiles, Capad, Cgpad;
   int fa, fb;
+  // narrow planes (Lw < 16, e.g. the 12x12 layers of the reference's 96x96 crops): G consecutive (sample, depth)
+  // slices are laid side by side, each with a 1-column zero gutter on either side, into a virtual lattice of
+  // width G*(Lw+2) -- a pure index map in the fetch; dY is zero in the gutters, so whatever the transform
+  // multiplies it with drops out.  G = 0: plain lattice.
+  int G, Lw2, nslices, rcp;
   float* slabs;      // [splits][KD][16][Capad][Cgpad]
   float* slab_bias;  // [splits][Capad] or null: per-split column sums of dY (bias gradient)
 };
@@ -104,30 +109,64 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
     int it = it0 + (live ? st : 0);
     const int bw_ = it % p.nb_w; it /= p.nb_w;
     const int bh_ = it % p.nb_h; it /= p.nb_h;
-    const int od = it % d.Ld;
-    const int n = it / d.Ld;
     const int oh0 = bh_ * RH, ow0 = bw_ * RW;
-    const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
-    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.l) + (int64_t)n * l_img, 0, l_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.g) + (int64_t)n * g_img, 0, g_bytes, 0x00020000);
-    const bool dok = live & ((unsigned)id < (unsigned)d.Dg);
+    const int doff = d.bd + d.td.off0 + d.td.offs * jd;
+    if (p.G == 0) {
+      const int od = it % d.Ld;
+      const int n = it / d.Ld;
+      const int id = od + doff;
+      const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(d.l) + (int64_t)n * l_img, 0, l_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(d.g) + (int64_t)n * g_img, 0, g_bytes, 0x00020000);
+      const bool dok = live & ((unsigned)id < (unsigned)d.Dg);
 #pragma unroll
-    for (int i = lo; i < hi; ++i) {
-      int kind, row, cw, q;
-      piece(i, kind, row, cw, q);
-      if (i < NPY) {
-        const int gh = oh0 + row, gw = ow0 + cw;
-        const bool ok = live & ((ca0 + 4 * q) < d.Ca) & (gh < d.Lh) & (gw < d.Lw);
-        const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * q) * 4u;
-        rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : l_bytes, 0, 0));
-      } else {
-        const int ih = oh0 - 1 + row, iw = ow0 - 1 + cw;
-        const bool ok = dok & (kind == 1) & ((cg0 + 4 * q) < d.Cg) & ((unsigned)ih < (unsigned)d.Hg) &
-                        ((unsigned)iw < (unsigned)d.Wg);
-        const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * q) * 4u;
-        rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : g_bytes, 0, 0));
+      for (int i = lo; i < hi; ++i) {
+        int kind, row, cw, q;
+        piece(i, kind, row, cw, q);
+        if (i < NPY) {
+          const int gh = oh0 + row, gw = ow0 + cw;
+          const bool ok = live & ((ca0 + 4 * q) < d.Ca) & (gh < d.Lh) & (gw < d.Lw);
+          const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * q) * 4u;
+          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : l_bytes, 0, 0));
+        } else {
+          const int ih = oh0 - 1 + row, iw = ow0 - 1 + cw;
+          const bool ok = dok & (kind == 1) & ((cg0 + 4 * q) < d.Cg) & ((unsigned)ih < (unsigned)d.Hg) &
+                          ((unsigned)iw < (unsigned)d.Wg);
+          const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * q) * 4u;
+          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : g_bytes, 0, 0));
+        }
+      }
+    } else {
+      // virtual wide lattice: column cv -> slice it*G + cv / (Lw+2), plane column cv % (Lw+2) - 1
+      const int sg = it * p.G;
+      const uint32_t lt = (uint32_t)d.N * l_bytes, gt = (uint32_t)d.N * g_bytes;  // whole tensors (< 4 GiB, planner)
+      const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.l), 0, lt, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.g), 0, gt, 0x00020000);
+#pragma unroll
+      for (int i = lo; i < hi; ++i) {
+        int kind, row, cw, q;
+        piece(i, kind, row, cw, q);
+        const bool isy = i < NPY;
+        const int cv = isy ? ow0 + cw : ow0 - 1 + cw;
+        const int cvc = cv < 0 ? 0 : cv;
+        const int s_ = (cvc * p.rcp) >> 16;                 // cv / (Lw+2) for cv < 4096
+        const int c = cvc - s_ * p.Lw2 - 1;
+        const int slice = sg + s_;
+        const int n = slice / d.Ld, od = slice - n * d.Ld;
+        const bool sok = live & (cv >= 0) & (s_ < p.G) & (slice < p.nslices) & ((unsigned)c < (unsigned)d.Lw);
+        if (isy) {
+          const int gh = oh0 + row;
+          const bool ok = sok & ((ca0 + 4 * q) < d.Ca) & (gh < d.Lh);
+          const uint32_t off = (uint32_t)((((n * d.Ld + od) * d.Lh + gh) * d.Lw + c) * d.ldl + ca0 + 4 * q) * 4u;
+          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : lt, 0, 0));
+        } else {
+          const int ih = oh0 - 1 + row, id = od + doff;
+          const bool ok = sok & (kind == 1) & ((cg0 + 4 * q) < d.Cg) & ((unsigned)ih < (unsigned)d.Hg) &
+                          ((unsigned)id < (unsigned)d.Dg);
+          const uint32_t off = (uint32_t)((((n * d.Dg + id) * d.Hg + ih) * d.Wg + c) * d.ldg + cg0 + 4 * q) * 4u;
+          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : gt, 0, 0));
+        }
       }
     }
   };
@@ -387,12 +426,29 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   if (d.td.count < 1 || d.td.count > 3) return false;
   if (d.Hg != d.Lh || d.Wg != d.Lw) return false;
   if (d.Ca < 16 || d.Cg < 16 || d.Ca % 4 || d.Cg % 4) return false;
-  if (d.Lh < 4 || d.Lw < 16) return false;
+  if (d.Lh < 4 || d.Lw < 6) return false;
   p.d = d;
   p.nb_h = (d.Lh + RH - 1) / RH;
-  p.nb_w = (d.Lw + RW - 1) / RW;
-  if ((int64_t)p.nb_h * RH * p.nb_w * RW * 100 > (int64_t)d.Lh * d.Lw * 134) return false;  // 24 x 24 (1.333) is in
-  const int64_t items = (int64_t)d.N * d.Ld * p.nb_h * p.nb_w;
+  p.G = 0;
+  int64_t items;
+  if (d.Lw >= 16) {
+    p.nb_w = (d.Lw + RW - 1) / RW;
+    if ((int64_t)p.nb_h * RH * p.nb_w * RW * 100 > (int64_t)d.Lh * d.Lw * 134) return false;  // 24 x 24 (1.333) is in
+    items = (int64_t)d.N * d.Ld * p.nb_h * p.nb_w;
+  } else {
+    // narrow planes: 8 slices side by side (see WWParams::G); whole-tensor buffer offsets must fit 32 bits
+    p.G = 8;
+    p.Lw2 = d.Lw + 2;
+    p.rcp = (65536 + p.Lw2 - 1) / p.Lw2;
+    p.nslices = d.N * d.Ld;
+    const int64_t groups = ((int64_t)p.nslices + p.G - 1) / p.G;
+    p.nb_w = (p.G * p.Lw2 + RW - 1) / RW;
+    if ((int64_t)groups * p.nb_h * RH * p.nb_w * RW * 100 > (int64_t)p.nslices * d.Lh * d.Lw * 140) return false;
+    if ((int64_t)d.N * d.Ld * d.Lh * d.Lw * d.ldl * 4 >= (1ll << 32) - 64 ||
+        (int64_t)d.N * d.Dg * d.Hg * d.Wg * d.ldg * 4 >= (1ll << 32) - 64)
+      return false;
+    items = groups * p.nb_h * p.nb_w;
+  }
   if (items >= (1ll << 30) || items < 4) return false;
   p.items = (int)items;
   p.fa = (d.Ca <= 32) ? 1 : 2;  // 32-channel sides take a single 32-wide group
