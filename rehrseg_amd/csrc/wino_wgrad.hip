@@ -448,6 +448,7 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
         (int64_t)d.N * d.Dg * d.Hg * d.Wg * d.ldg * 4 >= (1ll << 32) - 64)
       return false;
     items = groups * p.nb_h * p.nb_w;
+    if (items < 128) return false;  // too few stages to split over the chip: the slab kernel's finer split-K wins
   }
   if (items >= (1ll << 30) || items < 4) return false;
   p.items = (int)items;

@@ -128,9 +128,9 @@ WINO_WGRAD = [  # weight gradients in the transform domain: >= 64 channels both 
     (64, 32, (3, 3, 3), (1, 1, 1), (1, 4, 8, 32)),       # 1 x 2 groups
     (32, 64, (3, 3, 3), (1, 1, 1), (1, 4, 12, 16)),      # 2 x 1 groups
     (32, 16, (3, 3, 3), (1, 1, 1), (2, 4, 16, 32)),      # 16 output channels padded to one 32-wide group (SR head)
-    (64, 64, (3, 3, 3), (1, 1, 1), (8, 4, 12, 12)),      # narrow planes: 8 slices side by side in a virtual lattice
-    (128, 64, (1, 3, 3), (0, 1, 1), (8, 2, 8, 8)),       # narrow planes, 16 slices = two groups, one depth tap
-    (64, 128, (3, 3, 3), (1, 1, 1), (15, 1, 12, 10)),    # narrow planes, 15 slices (last group partial), width 10
+    (64, 64, (3, 3, 3), (1, 1, 1), (16, 4, 12, 12)),     # narrow planes: 8 slices side by side in a virtual lattice
+    (128, 64, (1, 3, 3), (0, 1, 1), (52, 2, 8, 8)),      # narrow planes, 104 slices = 13 groups, one depth tap
+    (64, 128, (3, 3, 3), (1, 1, 1), (63, 1, 12, 10)),    # narrow planes, 63 slices (last group partial), width 10
 ]
 
 
