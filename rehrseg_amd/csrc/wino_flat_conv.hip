@@ -251,8 +251,8 @@ bool plan_flat(const rehr_gather_gemm_desc& d, FlatParams& p) {
   if ((ntiles + 63) / 64 * (d.Npad / 64) < 128) return false;
   p.ns = (64 % p.tps == 0) ? 64 / p.tps : 63 / p.tps + 2;
   if (p.ns > NSMAX) return false;
-  p.PH = d.Lh + 2;
-  const int PW = d.Lw + 2;
+  p.PH = 2 * p.nth + 2;           // the last tile reads patch rows 2*nth-2 .. 2*nth+1 (odd extents: one zero row more)
+  const int PW = 2 * p.ntw + 2;
   p.PWs = PW;
   p.nev = (PW + 1) / 2;
   p.RP = PW * LDF + 4;

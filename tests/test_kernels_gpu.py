@@ -101,6 +101,7 @@ WINO = [  # Cin, Cout, K, pad, dims, expected kernel launches through the Winogr
     (128, 128, (3, 3, 3), (1, 1, 1), (32, 4, 12, 12)),  # small planes: flattened tiles, 36 per slice, 3 slices / block
     (128, 128, (3, 3, 3), (1, 1, 1), (64, 4, 8, 8)),    # flattened tiles, 16 per slice (4 whole slices per block)
     (128, 128, (3, 3, 3), (1, 1, 1), (42, 3, 14, 10)),  # flattened tiles, 35 per slice, last block partly empty
+    (128, 128, (3, 3, 3), (1, 1, 1), (40, 3, 13, 11)),  # flattened tiles, odd extents: half-empty edge tiles
     (48, 128, (1, 3, 3), (0, 1, 1), (120, 2, 12, 12)),  # flattened tiles, one depth tap, half last chunk
 ]
 
