@@ -834,18 +834,30 @@ __global__ __launch_bounds__(256) void thin_bias_partial_kernel(const float* __r
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void small_cout_wgrad_reduce_kernel(const float* __restrict__ slab, int strips, int64_t nw,
-                                               float* __restrict__ dw, const float* __restrict__ bpart,
-                                               int bblocks, int C, float* __restrict__ dbias) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < strips; ++k) s += slab[(int64_t)k * nw + i];
-    dw[i] = s;
+// dw[i] = sum over strips of slab[k][i], in a fixed order: a block owns 16 consecutive weights, its 16 thread
+// groups walk interleaved strips (a thread per weight looping over thousands of strips serially took 1 ms)
+__global__ __launch_bounds__(256) void small_cout_wgrad_reduce_kernel(const float* __restrict__ slab, int strips,
+                                                                      int64_t nw, float* __restrict__ dw,
+                                                                      const float* __restrict__ bpart, int bblocks,
+                                                                      int C, float* __restrict__ dbias) {
+  __shared__ float part[16][16];
+  const int wl = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + wl;
+  float s = 0.f;
+  if (i < nw)
+    for (int k = sg; k < strips; k += 16) s += slab[(int64_t)k * nw + i];
+  part[sg][wl] = s;
+  __syncthreads();
+  if (sg == 0 && i < nw) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][wl];
+    dw[i] = t;
   }
   if (dbias != nullptr && blockIdx.x == 0 && threadIdx.x < C) {
-    float s = 0.f;
-    for (int k = 0; k < bblocks; ++k) s += bpart[(int64_t)k * 4 + threadIdx.x];
-    dbias[threadIdx.x] = s;
+    float t = 0.f;
+    for (int k = 0; k < bblocks; ++k) t += bpart[(int64_t)k * 4 + threadIdx.x];
+    dbias[threadIdx.x] = t;
   }
 }
 
@@ -980,7 +992,7 @@ extern "C" int rehr_conv_small_cout_wgrad_f32(const rehr_direct_conv_desc* dp, f
   if (dbias != nullptr)
     hipLaunchKernelGGL(thin_bias_partial_kernel, dim3(SC_BIAS_BLOCKS), dim3(256), 0, st, d.y, d.ldy, d.Cout,
                        (int64_t)d.N * d.Do * d.Ho * d.Wo, bpart);
-  hipLaunchKernelGGL(small_cout_wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, workspace,
+  hipLaunchKernelGGL(small_cout_wgrad_reduce_kernel, dim3((unsigned)((nw + 15) / 16)), dim3(256), 0, st, workspace,
                      strips, nw, dw, bpart, SC_BIAS_BLOCKS, d.Cout, dbias);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
