@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=128, help="patch edge (128 = BASELINE config)")
-    ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref"], default="flavr",
+    ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref", "cfg4"], default="flavr",
                     help="flavr = configs[1] (headline); seg = configs[2] (SegModel 2x1x128^3, secondary); "
                          "flavr_ref = the reference's own stage-1 training shape, UNet_3D_3D(2,..,4,4) on "
                          "(B,2,4,96,96) with the UASR head (configs/brain.yaml)")
@@ -148,6 +148,45 @@ def main():
         def step():
             return train_sr_step(model, _Opt(opt, pp), None, x.clone(), hr, l1, bd, 4.0, 4, True,
                                  grad_sync=pp.reduce_gradients)
+    elif args.workload == "cfg4":
+        # BASELINE.json configs[3]: the joint stage-2 step (train_all.py:519-556), 1 LR patch per GPU: frozen FLAVR
+        # teacher (D-1 windows, batched, truncated after the consumed level) + SegModel student on the
+        # distillation-compatible anisotropic plan + Distiller, uncertainty-weighted CE / DC+CE, SGD
+        import itertools
+        import torch.nn as nn
+        from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+        from rehrseg_amd.models.seg_model import Distiller, SegModel
+        from rehrseg_amd.train_steps import train_segsr_step
+        from rehrseg_amd.utils.seg_utils import _build_loss
+        torch.manual_seed(0)
+        teacher = UNet_3D_3D(2, "unet_18", 4, 4, use_uncertainty=True).to(dev).eval()
+        for q in teacher.parameters():
+            q.requires_grad_(False)
+        student = SegModel(input_channels=1, num_classes=2, n_stages=6, upscale=4,
+                           features_per_stage=[32, 64, 128, 256, 320, 320], conv_op=nn.Conv3d,
+                           kernel_sizes=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+                           strides=[[1, 1, 1], [1, 2, 2], [1, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2]],
+                           n_conv_per_stage=[2] * 6, n_conv_per_stage_decoder=[2] * 5, conv_bias=True,
+                           norm_op=nn.InstanceNorm3d, norm_op_kwargs={"eps": 1e-5, "affine": True}, dropout_op=None,
+                           dropout_op_kwargs=None, nonlin=nn.LeakyReLU, nonlin_kwargs={"inplace": True},
+                           deep_supervision=False).to(dev)
+        dist_m = Distiller(64, 64, lambda_l1=0.0, lambda_cosine=1.0, lambda_structure=1.0).to(dev)
+        model = nn.ModuleDict({"student": student, "distiller": dist_m})
+        pp = PatchParallel(model)
+        opt = torch.optim.SGD(itertools.chain(student.parameters(), dist_m.parameters()), lr=1e-2, momentum=0.99,
+                              nesterov=True, weight_decay=3e-5)
+        img = torch.randn(1, 1, size, size, size, generator=g).to(dev)
+        lab_lr = torch.randint(0, 2, (1, 1, size, size, size), generator=g).float().to(dev)
+        lab_hr = torch.randint(0, 2, (1, 1, 4 * size, size, size), generator=g).float().to(dev)
+        unc = (1.0 - torch.randint(0, 256, (1, 1, size, size, size), generator=g).float() / 255.0 * 0.99).to(dev)
+        patches_per_step = 1
+        workload = (f"joint stage-2 step: FLAVR teacher (no-grad, {size - 1} windows batched) + SegModel student "
+                    f"(anisotropic plan, upscale 4) + Distiller + SGD, 1x1x{size}^3 LR patch per GPU, random-init weights")
+        l_lr, l_hr = _build_loss(False, weight_dice=0), _build_loss(False, weight_dice=1)
+
+        def step():
+            return train_segsr_step(student, teacher, dist_m, _Opt(opt, pp), img.clone(), lab_lr, lab_hr, unc, l_lr, l_hr,
+                                    grad_sync=pp.reduce_gradients)
     else:
         model = build_seg_model(dev)
         pp = PatchParallel(model)

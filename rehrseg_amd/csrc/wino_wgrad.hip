@@ -15,11 +15,14 @@
 //             wave instruction = 64 distinct banks).  The MFMA k index is the TILE, so a lane
 //             (= channel) needs 8 / 10 consecutive columns per row: two or three 128/64-bit reads
 //             instead of 8 / 10 scalar ones (20 LDS reads per k-group instead of 72).
-//   k-group = 8 tiles (one tile row): 4 quarters (fa, fb) of 16 MFMAs; the operands of the next
-//             k-group are read + transformed one set per quarter, slotted between the MFMAs.
+//   k-group = 8 tiles (one tile row) = 4 quarters (fa, fb) of 16 MFMAs = 16 steps of 4 MFMAs.  The loop
+//             body is ONE basic block (counter-walked items, predicated loads, a spare LDS pad for the
+//             threads without a share of the last staging piece): fetch and staging run in the shadow
+//             of the MFMAs instead of between them, laid out per step (see kgroup).
 #include "common.h"
 #include "wgrad_shared.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +41,7 @@ struct WWParams {
   // width G*(Lw+2) -- a pure index map in the fetch; dY is zero in the gutters, so whatever the transform
   // multiplies it with drops out.  G = 0: plain lattice.
   int G, Lw2, nslices, rcp;
+  uint32_t rcp_ld;   // ceil(2^32 / Ld)
   float* slabs;      // [splits][KD][16][Capad][Cgpad]
   float* slab_bias;  // [splits][Capad] or null: per-split column sums of dY (bias gradient)
 };
@@ -60,7 +64,7 @@ struct WWCfg {
   static constexpr int MINB = (FA * FB == 4) ? 1 : ((FA * FB == 2) ? 1 : 2);
 };
 
-template <int FA, int FB>
+template <int FA, int FB, bool VIRT>
 __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(const WWParams p) {
   using C = WWCfg<FA, FB>;
   constexpr int WP = C::WP, CA = C::CA, CG = C::CG, YBUF = C::YBUF, BUF = C::BUF;
@@ -104,16 +108,36 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
       kind = (tid < 96 * FB) ? 1 : 2; row = rest >> 1; cw = 16 + (rest & 1); q = tid % (8 * FB);
     }
   };
-  auto fetch = [&](int st, const int lo, const int hi) {  // pieces [lo, hi) of stage st
-    const bool live = st < nstages;
-    int it = it0 + (live ? st : 0);
-    const int bw_ = it % p.nb_w; it /= p.nb_w;
-    const int bh_ = it % p.nb_h; it /= p.nb_h;
-    const int oh0 = bh_ * RH, ow0 = bw_ * RW;
-    const int doff = d.bd + d.td.off0 + d.td.offs * jd;
-    if (p.G == 0) {
-      const int od = it % d.Ld;
-      const int n = it / d.Ld;
+  // The staged item (region bw_, bh_ of depth slice od of sample n -- or of slice group grp in the
+  // side-by-side mode) is walked with counters: no integer division and no branch inside the loop, so
+  // that the address arithmetic and the loads are ordinary instructions of the MFMA region they sit in.
+  int f_bw, f_bh, f_od, f_n, f_left = nstages;
+  {
+    int it = it0;
+    f_bw = it % p.nb_w; it /= p.nb_w;
+    f_bh = it % p.nb_h; it /= p.nb_h;
+    if constexpr (VIRT) { f_od = 0; f_n = it; } else { f_od = it % d.Ld; f_n = it / d.Ld; }
+  }
+  auto advance = [&]() {
+    --f_left;
+    const bool w_end = (f_bw + 1 == p.nb_w);
+    f_bw = w_end ? 0 : f_bw + 1;
+    const bool h_end = w_end & (f_bh + 1 == p.nb_h);
+    f_bh = w_end ? (h_end ? 0 : f_bh + 1) : f_bh;
+    if constexpr (VIRT) {
+      f_n += h_end ? 1 : 0;
+    } else {
+      const bool d_end = h_end & (f_od + 1 == d.Ld);
+      f_od = h_end ? (d_end ? 0 : f_od + 1) : f_od;
+      f_n += d_end ? 1 : 0;
+    }
+  };
+  const int doff = d.bd + d.td.off0 + d.td.offs * jd;
+  auto fetch = [&](const int lo, const int hi, const int base) {  // pieces [lo, hi) of the cursor's item -> rx[i - base]
+    const bool live = f_left > 0;
+    const int oh0 = f_bh * RH, ow0 = f_bw * RW;
+    if constexpr (!VIRT) {
+      const int od = f_od, n = live ? f_n : 0;
       const int id = od + doff;
       const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(d.l) + (int64_t)n * l_img, 0, l_bytes, 0x00020000);
@@ -128,18 +152,18 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
           const int gh = oh0 + row, gw = ow0 + cw;
           const bool ok = live & ((ca0 + 4 * q) < d.Ca) & (gh < d.Lh) & (gw < d.Lw);
           const uint32_t off = (uint32_t)(((od * d.Lh + gh) * d.Lw + gw) * d.ldl + ca0 + 4 * q) * 4u;
-          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : l_bytes, 0, 0));
+          rx[i - base] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, max(off, ok ? 0u : l_bytes), 0, 0));
         } else {
           const int ih = oh0 - 1 + row, iw = ow0 - 1 + cw;
           const bool ok = dok & (kind == 1) & ((cg0 + 4 * q) < d.Cg) & ((unsigned)ih < (unsigned)d.Hg) &
                           ((unsigned)iw < (unsigned)d.Wg);
           const uint32_t off = (uint32_t)(((id * d.Hg + ih) * d.Wg + iw) * d.ldg + cg0 + 4 * q) * 4u;
-          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : g_bytes, 0, 0));
+          rx[i - base] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, max(off, ok ? 0u : g_bytes), 0, 0));
         }
       }
     } else {
-      // virtual wide lattice: column cv -> slice it*G + cv / (Lw+2), plane column cv % (Lw+2) - 1
-      const int sg = it * p.G;
+      // virtual wide lattice: column cv -> slice grp*G + cv / (Lw+2), plane column cv % (Lw+2) - 1
+      const int sg = f_n * p.G;
       const uint32_t lt = (uint32_t)d.N * l_bytes, gt = (uint32_t)d.N * g_bytes;  // whole tensors (< 4 GiB, planner)
       const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.l), 0, lt, 0x00020000);
       const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.g), 0, gt, 0x00020000);
@@ -153,37 +177,37 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
         const int s_ = (cvc * p.rcp) >> 16;                 // cv / (Lw+2) for cv < 4096
         const int c = cvc - s_ * p.Lw2 - 1;
         const int slice = sg + s_;
-        const int n = slice / d.Ld, od = slice - n * d.Ld;
+        // slice / Ld: multiply-high by ceil(2^32 / Ld), exact below 65536 slices (planner); Ld = 1 has no 32-bit reciprocal
+        const int n = (d.Ld == 1) ? slice : (int)__umulhi((uint32_t)slice, p.rcp_ld);
+        const int od = slice - n * d.Ld;
         const bool sok = live & (cv >= 0) & (s_ < p.G) & (slice < p.nslices) & ((unsigned)c < (unsigned)d.Lw);
         if (isy) {
           const int gh = oh0 + row;
           const bool ok = sok & ((ca0 + 4 * q) < d.Ca) & (gh < d.Lh);
           const uint32_t off = (uint32_t)((((n * d.Ld + od) * d.Lh + gh) * d.Lw + c) * d.ldl + ca0 + 4 * q) * 4u;
-          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ok ? off : lt, 0, 0));
+          rx[i - base] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, max(off, ok ? 0u : lt), 0, 0));
         } else {
           const int ih = oh0 - 1 + row, id = od + doff;
           const bool ok = sok & (kind == 1) & ((cg0 + 4 * q) < d.Cg) & ((unsigned)ih < (unsigned)d.Hg) &
                           ((unsigned)id < (unsigned)d.Dg);
           const uint32_t off = (uint32_t)((((n * d.Dg + id) * d.Hg + ih) * d.Wg + c) * d.ldg + cg0 + 4 * q) * 4u;
-          rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : gt, 0, 0));
+          rx[i - base] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, max(off, ok ? 0u : gt), 0, 0));
         }
       }
     }
   };
-  auto stage = [&](int buf, const int lo, const int hi) {
+  // threads without a share of the last piece store to a spare pad behind the two buffers: no branch
+  float* const spare = smem + 2 * BUF + lane;
+  auto stage = [&](int buf, const int lo, const int hi, const int base) {
 #pragma unroll
     for (int i = lo; i < hi; ++i) {
       int kind, row, cw, q;
       piece(i, kind, row, cw, q);
-      if (i < NPY) {
-        float* dst = smem + buf + (row * CA + 4 * q) * WP + cw;
+      float* dst;
+      if (i < NPY) dst = smem + buf + (row * CA + 4 * q) * WP + cw;
+      else dst = (kind == 1) ? smem + buf + YBUF + (row * CG + 4 * q) * WP + cw : spare;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e * WP] = rx[i - lo][e];
-      } else if (kind == 1) {
-        float* dst = smem + buf + YBUF + (row * CG + 4 * q) * WP + cw;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e * WP] = rx[i - lo][e];
-      }
+      for (int e = 0; e < 4; ++e) dst[e * WP] = rx[i - base][e];
     }
   };
 
@@ -194,16 +218,20 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
   // Z[c][e] for 32 co: tiles 4*half + e, dY rows 2g, 2g+1, columns 8*half .. 8*half + 7
   const float* ybase = smem + col * WP + 8 * half;
   const float* xbase = smem + YBUF + col * WP + 8 * half;
-  auto prep_z = [&](int buf, const int g, const int fa, f32x4 (&Z)[4]) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  struct Raw { f32x4 a0, a1, b0, b1; f32x2_ a2, b2; };  // the LDS words of one operand set, untransformed
+  auto read_z = [&](int buf, const int g, const int fa, Raw& w) {
     const float* y0 = ybase + buf + ((2 * g) * CA + fa * 32) * WP;
     const float* y1 = y0 + CA * WP;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(y0), a1 = *reinterpret_cast<const f32x4*>(y0 + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(y1), b1 = *reinterpret_cast<const f32x4*>(y1 + 4);
+    w.a0 = *reinterpret_cast<const f32x4*>(y0); w.a1 = *reinterpret_cast<const f32x4*>(y0 + 4);
+    w.b0 = *reinterpret_cast<const f32x4*>(y1); w.b1 = *reinterpret_cast<const f32x4*>(y1 + 4);
+  };
+  auto xform_z = [&](const int fa, const Raw& w, f32x4 (&Z)[4]) {
     float z[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      z[k] = zka * a0[k] + zkb * b0[k];
-      z[4 + k] = zka * a1[k] + zkb * b1[k];
+      z[k] = zka * w.a0[k] + zkb * w.b0[k];
+      z[4 + k] = zka * w.a1[k] + zkb * w.b1[k];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -216,22 +244,23 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
     bsum[fa] += (Z[1][0] + Z[1][1]) + (Z[1][2] + Z[1][3]);
   };
   // V[c][e] for 32 ci: patch rows 2g + i1, 2g + i2, columns 8*half .. 8*half + 9
-  typedef float f32x2_ __attribute__((ext_vector_type(2)));
-  auto prep_v = [&](int buf, const int g, const int fb, f32x4 (&V)[4]) {
+  auto read_v = [&](int buf, const int g, const int fb, Raw& w) {
     const float* xa = xbase + buf + ((2 * g + i1) * CG + fb * 32) * WP;
     const float* xb = xbase + buf + ((2 * g + i2) * CG + fb * 32) * WP;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa), a1 = *reinterpret_cast<const f32x4*>(xa + 4);
-    const f32x2_ a2 = *reinterpret_cast<const f32x2_*>(xa + 8);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(xb), b1 = *reinterpret_cast<const f32x4*>(xb + 4);
-    const f32x2_ b2 = *reinterpret_cast<const f32x2_*>(xb + 8);
+    w.a0 = *reinterpret_cast<const f32x4*>(xa); w.a1 = *reinterpret_cast<const f32x4*>(xa + 4);
+    w.a2 = *reinterpret_cast<const f32x2_*>(xa + 8);
+    w.b0 = *reinterpret_cast<const f32x4*>(xb); w.b1 = *reinterpret_cast<const f32x4*>(xb + 4);
+    w.b2 = *reinterpret_cast<const f32x2_*>(xb + 8);
+  };
+  auto xform_v = [&](const Raw& w, f32x4 (&V)[4]) {
     float R[10];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      R[k] = a0[k] + s2 * b0[k];
-      R[4 + k] = a1[k] + s2 * b1[k];
+      R[k] = w.a0[k] + s2 * w.b0[k];
+      R[4 + k] = w.a1[k] + s2 * w.b1[k];
     }
-    R[8] = a2[0] + s2 * b2[0];
-    R[9] = a2[1] + s2 * b2[1];
+    R[8] = w.a2[0] + s2 * w.b2[0];
+    R[9] = w.a2[1] + s2 * w.b2[1];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       V[0][e] = R[2 * e] - R[2 * e + 2];
@@ -240,18 +269,21 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
       V[3][e] = R[2 * e + 1] - R[2 * e + 3];
     }
   };
-  // the FA + FB operand sets of a k-group, interleaved Z0 V0 Z1 V1, spread over its FA*FB quarters
-  auto prep_set = [&](const int j, int buf, const int g, f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4]) {
-    // j-th existing entry of (Z0, V0, Z1, V1)
-    if constexpr (FA == 2 && FB == 2) {
-      if (j & 1) prep_v(buf, g, j >> 1, VS[j >> 1]); else prep_z(buf, g, j >> 1, ZS[j >> 1]);
-    } else if constexpr (FA == 1 && FB == 1) {
-      if (j == 0) prep_z(buf, g, 0, ZS[0]); else prep_v(buf, g, 0, VS[0]);
-    } else if constexpr (FA == 1 && FB == 2) {
-      if (j == 0) prep_z(buf, g, 0, ZS[0]); else prep_v(buf, g, j - 1, VS[j - 1]);
-    } else {
-      if (j == 1) prep_v(buf, g, 0, VS[0]); else prep_z(buf, g, j >> 1, ZS[j >> 1]);
-    }
+  // the FA + FB operand sets of a k-group, in the order (Z0, V0, Z1, V1) of their first use
+  auto set_is_z = [](const int j) {
+    if constexpr (FA == 2 && FB == 2) return (j & 1) == 0;
+    else if constexpr (FA == 1) return j == 0;
+    else return j != 1;
+  };
+  auto set_idx = [](const int j) {
+    if constexpr (FA == 1 && FB == 2) return j == 0 ? 0 : j - 1;
+    else return j >> 1;
+  };
+  auto prep_read = [&](const int j, int buf, const int g, Raw& w) {
+    if (set_is_z(j)) read_z(buf, g, set_idx(j), w); else read_v(buf, g, set_idx(j), w);
+  };
+  auto prep_xform = [&](const int j, const Raw& w, f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4]) {
+    if (set_is_z(j)) xform_z(set_idx(j), w, ZS[set_idx(j)]); else xform_v(w, VS[set_idx(j)]);
   };
 
   f32x16 acc[FA][FB][4];
@@ -263,58 +295,78 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[fa][fb][c][k] = 0.f;
-  auto mfma16 = [&](const int fa, const int fb, const f32x4 (&Z)[4], const f32x4 (&V)[4]) {
+  // A k-group = NS steps of 4 MFMAs (one tile pair e of one quarter), each its own scheduling region.  With one
+  // wave per SIMD nothing hides a wait but the wave's own MFMAs in flight, so the work between them is laid out
+  // by hand: the LDS reads of an operand set are issued SPC steps before its transform, the LDS stores of the
+  // pieces fetched during the previous k-group go into the first half of the steps, their refill (address
+  // arithmetic + global loads) into the second half, the cursor moves at the end.  Everything is branch-free.
+  constexpr int NS = 4 * C::NQ, SPC = (NS >= 16) ? 2 : 1, NPREP = C::NPREP;
+  auto kgroup = [&](f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4], int pbuf, const int pg, f32x4 (&ZN)[FA][4],
+                    f32x4 (&VN)[FB][4], int sbuf, auto second_) {
+    // first k-group of a stage: stores the second half of the pieces, refills the first half; second: vice versa
+    constexpr bool second = decltype(second_)::value;
+    constexpr int slo = second ? 0 : NPA, ns = second ? NPA : NP - NPA;
+    constexpr int flo = second ? NPA : 0, nf = second ? NP - NPA : NPA;
+    Raw raw[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int s_ = 0; s_ < NS; ++s_) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NPREP; ++j) {
+        if (s_ == (j + 1) * SPC) prep_xform(j, raw[j & 1], ZN, VN);
+        if (s_ == j * SPC) prep_read(j, pbuf, pg, raw[j & 1]);
+      }
+#pragma unroll
+      for (int k = 0; k < ns; ++k)
+        if (s_ == k * (NS / 2) / ns) stage(sbuf, slo + k, slo + k + 1, slo);
+#pragma unroll
+      for (int k = 0; k < nf; ++k)
+        if (s_ == NS / 2 + k * (NS / 2) / nf) fetch(flo + k, flo + k + 1, flo);
+      if (second && s_ == NS - 1) advance();
+      const int qi = s_ >> 2, e = s_ & 3;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        acc[fa][fb][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Z[c][e], V[c][e], acc[fa][fb][c], 0, 0, 0);
-  };
-  // One scheduling region per quarter: 16 MFMAs and the preparation of the next k-group's operand
-  // set(s) (LDS reads, staging traffic, the transforms' VALU) interleave freely inside it; imposing
-  // an explicit sched_group_barrier order measured the same.
-  auto kgroup = [&](f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4], int pbuf, const int pg, f32x4 (&ZN)[FA][4],
-                    f32x4 (&VN)[FB][4], auto&& extra) {
-#pragma unroll
-    for (int qi = 0; qi < C::NQ; ++qi) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < C::NPREP; ++j)
-        if (j * C::NQ / C::NPREP == qi) prep_set(j, pbuf, pg, ZN, VN);
-      if (qi == 0) extra();
-      mfma16(qi / FB, qi % FB, ZS[qi / FB], VS[qi % FB]);
-      __builtin_amdgcn_sched_barrier(0);
+        acc[qi / FB][qi % FB][c] =
+            __builtin_amdgcn_mfma_f32_32x32x2f32(ZS[qi / FB][c][e], VS[qi % FB][c][e], acc[qi / FB][qi % FB][c], 0, 0, 0);
+      // empty anchor on the four accumulators: instruction selection may not let the MFMAs drift out of their
+      // step (measured: -2 %; anchoring the transforms or the address arithmetic the same way measured worse).
+      // The two-blocks-per-CU shape has a second wave to fill gaps and runs better without it.
+      if constexpr (C::MINB == 1)
+      asm volatile("" : "+a"(acc[qi / FB][qi % FB][0]), "+a"(acc[qi / FB][qi % FB][1]), "+a"(acc[qi / FB][qi % FB][2]),
+                        "+a"(acc[qi / FB][qi % FB][3]));
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
+  using std::integral_constant;
 
   f32x4 ZP[FA][4], VP[FB][4], ZQ[FA][4], VQ[FB][4];
   if (nstages > 0) {
     // prologue: stage 0 complete in buffer 0, first half of stage 1 in buffer 1, second half in flight
-    fetch(0, 0, NPA);
-    stage(0, 0, NPA);
-    fetch(0, NPA, NP);
-    stage(0, NPA, NP);
-    fetch(1, 0, NPA);
-    stage(BUF, 0, NPA);
-    fetch(1, NPA, NP);
+    fetch(0, NPA, 0);
+    stage(0, 0, NPA, 0);
+    fetch(NPA, NP, NPA);
+    stage(0, NPA, NP, NPA);
+    advance();
+    fetch(0, NPA, 0);
+    stage(BUF, 0, NPA, 0);
+    fetch(NPA, NP, NPA);
+    advance();
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < C::NPREP; ++j) prep_set(j, 0, 0, ZP, VP);
+    for (int j = 0; j < NPREP; ++j) {
+      Raw w;
+      prep_read(j, 0, 0, w);
+      prep_xform(j, w, ZP, VP);
+    }
 
     for (int st = 0; st < nstages; ++st) {
       const int cur = (st & 1) * BUF, nxt = cur ^ BUF;
       // tile row 0 with set P; set Q <- tile row 1 of this stage.  Staging: second half of stage
       // st+1 lands in nxt (free since the previous midpoint), first half of st+2 is fetched.
-      kgroup(ZP, VP, cur, 1, ZQ, VQ, [&]() {
-        stage(nxt, NPA, NP);
-        fetch(st + 2, 0, NPA);
-      });
+      kgroup(ZP, VP, cur, 1, ZQ, VQ, nxt, integral_constant<bool, false>{});
       // midpoint: nobody reads `cur` any more, stage st+1 is complete in `nxt`
       __syncthreads();
-      kgroup(ZQ, VQ, nxt, 0, ZP, VP, [&]() {
-        stage(cur, 0, NPA);
-        fetch(st + 2, NPA, NP);
-      });
+      kgroup(ZQ, VQ, nxt, 0, ZP, VP, cur, integral_constant<bool, true>{});
     }
   }
 
@@ -397,17 +449,17 @@ __global__ void wino_wgrad_reduce_kernel(const WWParams p) {
   }
 }
 
-template <int FA, int FB>
+template <int FA, int FB, bool VIRT>
 int launch_ww(const WWParams& p, dim3 grid, hipStream_t stream) {
-  const size_t smem = (size_t)2 * WWCfg<FA, FB>::BUF * sizeof(float);
+  const size_t smem = ((size_t)2 * WWCfg<FA, FB>::BUF + 128) * sizeof(float);  // + the spare pad of stage()
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<FA, FB, VIRT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
       return REHR_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wino_wgrad_kernel<FA, FB>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((wino_wgrad_kernel<FA, FB, VIRT>), grid, dim3(256), smem, stream, p);
   return REHR_OK;
 }
 
@@ -441,6 +493,8 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
     p.Lw2 = d.Lw + 2;
     p.rcp = (65536 + p.Lw2 - 1) / p.Lw2;
     p.nslices = d.N * d.Ld;
+    if (p.nslices >= 65536) return false;
+    p.rcp_ld = d.Ld > 1 ? (uint32_t)((0x100000000ull + d.Ld - 1) / d.Ld) : 0u;
     const int64_t groups = ((int64_t)p.nslices + p.G - 1) / p.G;
     p.nb_w = (p.G * p.Lw2 + RW - 1) / RW;
     if ((int64_t)groups * p.nb_h * RH * p.nb_w * RW * 100 > (int64_t)p.nslices * d.Lh * d.Lw * 140) return false;
@@ -510,10 +564,11 @@ int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
   p.slab_bias = d.dbias ? d.workspace + slab_floats(p) : nullptr;
   dim3 grid(p.splits, p.a_tiles * p.c_tiles, d.td.count);
   int rc;
-  if (p.fa == 2 && p.fb == 2) rc = launch_ww<2, 2>(p, grid, stream);
-  else if (p.fa == 1 && p.fb == 1) rc = launch_ww<1, 1>(p, grid, stream);
-  else if (p.fa == 1) rc = launch_ww<1, 2>(p, grid, stream);
-  else rc = launch_ww<2, 1>(p, grid, stream);
+  const bool virt = p.G != 0;
+  if (p.fa == 2 && p.fb == 2) rc = virt ? launch_ww<2, 2, true>(p, grid, stream) : launch_ww<2, 2, false>(p, grid, stream);
+  else if (p.fa == 1 && p.fb == 1) rc = virt ? launch_ww<1, 1, true>(p, grid, stream) : launch_ww<1, 1, false>(p, grid, stream);
+  else if (p.fa == 1) rc = virt ? launch_ww<1, 2, true>(p, grid, stream) : launch_ww<1, 2, false>(p, grid, stream);
+  else rc = virt ? launch_ww<2, 1, true>(p, grid, stream) : launch_ww<2, 1, false>(p, grid, stream);
   if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)d.td.count * d.Ca * d.Cg;
   int blocks = (int)((total + 255) / 256);
