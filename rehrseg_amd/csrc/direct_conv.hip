@@ -572,12 +572,14 @@ __global__ __launch_bounds__(256) void small_cout_wgrad_kernel(const rehr_direct
 // of 64 scattered 16-byte pieces.  Partial sums are combined across the CG lanes at the end.
 template <int CO, int CG>
 __global__ __launch_bounds__(256) void small_cout_fwd_cg_kernel(const rehr_direct_conv_desc d) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [T][CO][Cin]
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [T][CO][Cin]; CO == 2: [T][Cin][2] (co pairs adjacent)
   const int T = d.KD * d.KH * d.KW;
   for (int i = threadIdx.x; i < CO * d.Cin * T; i += 256) {
     const int co = i / (d.Cin * T), rem = i - co * d.Cin * T;
     const int ci = rem / T, t = rem - ci * T;
-    wl[(t * CO + co) * d.Cin + ci] = (co < d.Cout) ? d.w[((int64_t)co * d.Cin + ci) * T + t] : 0.f;
+    const float v = (co < d.Cout) ? d.w[((int64_t)co * d.Cin + ci) * T + t] : 0.f;
+    if constexpr (CO == 2) wl[(t * d.Cin + ci) * 2 + co] = v;
+    else wl[(t * CO + co) * d.Cin + ci] = v;
   }
   __syncthreads();
   const int c4 = (threadIdx.x % CG) * 4;
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256) void small_cout_fwd_cg_kernel(const rehr_direc
         const int ih = oh - d.ph + kh;
         const bool rowok = live && (unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi;
         const float* xr = xn + ((int64_t)id * d.Hi + ih) * d.Wi * d.ldx;
-        const float* wr = wl + (kd * d.KH + kh) * d.KW * CO * d.Cin + c4;
+        const float* wr = wl + (kd * d.KH + kh) * d.KW * CO * d.Cin + (CO == 2 ? 2 * c4 : c4);
         f32x4 seg[SC_VOX + SC_MAXKW - 1];
 #pragma unroll
         for (int j = 0; j < SC_VOX + SC_MAXKW - 1; ++j) {
@@ -619,13 +621,30 @@ __global__ __launch_bounds__(256) void small_cout_fwd_cg_kernel(const rehr_direc
 #pragma unroll
         for (int kw = 0; kw < SC_MAXKW; ++kw) {
           if (kw < d.KW) {
-#pragma unroll
-            for (int c = 0; c < CO; ++c) {
-              const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (kw * CO + c) * d.Cin);
+            if constexpr (CO == 2) {
+              // both output channels of a (voxel, input channel) in one packed FMA: {x, x} * {w0, w1}
+              typedef float f32x2_ __attribute__((ext_vector_type(2)));
+              const f32x4 wa = *reinterpret_cast<const f32x4*>(wr + kw * 2 * d.Cin);      // ci c4, c4+1
+              const f32x4 wb = *reinterpret_cast<const f32x4*>(wr + kw * 2 * d.Cin + 4);  // ci c4+2, c4+3
+              const f32x2_ wp[4] = {{wa[0], wa[1]}, {wa[2], wa[3]}, {wb[0], wb[1]}, {wb[2], wb[3]}};
 #pragma unroll
               for (int v = 0; v < SC_VOX; ++v) {
                 const f32x4 xv = seg[v + kw];
-                acc[v][c] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+                f32x2_ a = {acc[v][0], acc[v][1]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a = __builtin_elementwise_fma(f32x2_{xv[e], xv[e]}, wp[e], a);
+                acc[v][0] = a[0];
+                acc[v][1] = a[1];
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < CO; ++c) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (kw * CO + c) * d.Cin);
+#pragma unroll
+                for (int v = 0; v < SC_VOX; ++v) {
+                  const f32x4 xv = seg[v + kw];
+                  acc[v][c] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+                }
               }
             }
           }

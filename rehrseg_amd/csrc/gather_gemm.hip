@@ -464,10 +464,18 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
       return REHR_EINVAL;  // (y may differ: split-K partials go to separate slabs)
   }
   hipStream_t st = (hipStream_t)stream;
+  if (count > 1 && descs[0].td.count > 3 && descs[0].wino_ws != nullptr) {
+    // tap-range parts of a split-K launch with many depth taps: all parts in one Winograd grid, or none
+    const int src = wino_conv_split_try(descs, count, st);
+    if (src != REHR_ENOSUP) return src;
+  }
   GGMulti pm;
   int n = 0;
   for (int i = 0; i < count; ++i) {
-    if (descs[i].wino_ws != nullptr) {  // fewer multiplications beat better tiling: Winograd first
+    // fewer multiplications beat better tiling: Winograd first -- except for the tap-range parts of a split-K
+    // launch (many depth taps, few tiles): one Winograd launch per part would run them one after the other on a
+    // quarter of the chip, the generic kernel runs all parts in one grid
+    if (descs[i].wino_ws != nullptr && !(count > 1 && descs[i].td.count > 3)) {
       int wrc = wino_conv_try(descs[i], st);
       if (wrc == REHR_ENOSUP) wrc = wino22_conv_try(descs[i], st);
       if (wrc == REHR_ENOSUP) wrc = wino_flat_conv_try(descs[i], st);

@@ -4,6 +4,8 @@
 #include "common.h"
 int64_t wino_workspace_bytes(const rehr_gather_gemm_desc& d);
 int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
+// split-K parts (depth-tap ranges of one layer, one slab each) in one launch of the big-tile kernel
+int wino_conv_split_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t stream);
 // F(2x2,2x2) variant for 2-tap phases / stride-2 4-tap gathers (wino22_conv.hip)
 int64_t wino22_workspace_bytes(const rehr_gather_gemm_desc& d);
 int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);

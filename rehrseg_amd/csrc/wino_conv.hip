@@ -33,6 +33,13 @@ struct WinoParams {
   int dh0, dw0;         // source offset of patch row/col 0 relative to the region origin (= -1 here)
   const float* up;      // U[jd][16][Npad][Cin]
   uint32_t up_bytes;
+  // split-K over depth-tap ranges (big-tile kernel only; feature_fuse: 128 depth taps on one output slice):
+  // grid.z = sample * nsplit + part, every part with its own taps, transformed weights and output slab
+  int nsplit;
+  rehr_axis_taps s_td[8];
+  const float* s_up[8];
+  uint32_t s_up_bytes[8];
+  float* s_y[8];
 };
 
 // U[jd][xi = r*4 + c][n][ci] = sum_{a,b} G[r][a] G[c][b] g'[a][b],  g'[dh+1][dw+1] = wp[tap with offsets (dh,dw)]
@@ -350,7 +357,12 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
-  const int n_img = blockIdx.z;
+  const int part = (p.nsplit > 1) ? (int)(blockIdx.z % p.nsplit) : 0;
+  const int n_img = (p.nsplit > 1) ? (int)(blockIdx.z / p.nsplit) : (int)blockIdx.z;
+  const rehr_axis_taps td = (p.nsplit > 1) ? p.s_td[part] : p.d.td;
+  const float* const up = (p.nsplit > 1) ? p.s_up[part] : p.up;
+  const uint32_t up_bytes = (p.nsplit > 1) ? p.s_up_bytes[part] : p.up_bytes;
+  float* const yout = (p.nsplit > 1) ? p.s_y[part] : p.d.y;
   const int nt0 = blockIdx.y * 2, n0 = blockIdx.y * 64;
   int b = xcd_remap(blockIdx.x, gridDim.x);
   const int bw_ = b % p.nb_w; b /= p.nb_w;
@@ -385,9 +397,9 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   f32x4 rx[NXA];
   // depth taps whose source slice lies outside the volume contribute nothing for this whole block
   // (od is block-uniform): walk only the valid range [jd_lo, jd_hi]
-  int jd_lo = d.td.count, jd_hi = -1;
-  for (int j = 0; j < d.td.count; ++j) {
-    const int id = od + d.bd + d.td.off0 + d.td.offs * j;
+  int jd_lo = td.count, jd_hi = -1;
+  for (int j = 0; j < td.count; ++j) {
+    const int id = od + d.bd + td.off0 + td.offs * j;
     if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
   }
   const int items = p.kchunks * max(0, jd_hi - jd_lo + 1);
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
     const bool live = (t.chunk < p.kchunks) & (items > 0);
     const int jd = t.jd;
     const int cc = (live ? t.chunk : 0) * 32;
-    const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
+    const int id = od + d.bd + td.off0 + td.offs * jd;
     const bool first = cc < d.c1;
     const float* src = first ? d.x1 : d.x2;
     const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   auto stage = [&](int buf, const int lo, const int hi) { stage_from(rx, buf, lo, hi); };
 
   const __amdgpu_buffer_rsrc_t rsu =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(up), 0, up_bytes, 0x00020000);
   const int NT = d.Npad / 32;
   const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
   // the fragment address is wave-uniform except for the lane's 16 bytes: scalar offset operand, no VALU
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
 
   VFrag VA, VB;
   f32x4 u0[2][4], u1[2][4];
-  Item ci = {0, min(jd_lo, d.td.count - 1)}, ni = ci;
+  Item ci = {0, min(jd_lo, td.count - 1)}, ni = ci;
   {  // item 0: all 11 pieces in flight at once (u1's registers are free here)
     fetch(ci, 0, NXA);
     f32x4 (&rx2)[NXA] = reinterpret_cast<f32x4 (&)[NXA]>(u1);
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   // the lane's first output voxel; every other one is a compile-time multiple of two uniform steps
   // away (tile row = fm*4 + (q>>2), tile column = (q&3) + 4*half), so interior blocks store with
   // scalar offsets and no per-element predicate
-  float* ybase = d.y + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
+  float* ybase = yout + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
                  n0 + col;
   const int64_t rowstep = 2 * (int64_t)d.Wy * d.ldy, colstep = 2 * (int64_t)d.ldy;
   const bool interior = (oh0 + 16 <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 64 <= d.Cout);
@@ -916,7 +928,7 @@ int64_t wino_workspace_bytes(const rehr_gather_gemm_desc& d) {
   if (d.osd != 1 || d.osh != 1 || d.osw != 1 || d.obd || d.obh || d.obw) return 0;
   if (d.Ld != d.Dy || d.Lh != d.Hy || d.Lw != d.Wy) return 0;
   if (!three_taps(d.th, d.bh) || !three_taps(d.tw, d.bw)) return 0;
-  if (d.td.count < 1 || d.td.count > 3) return 0;
+  if (d.td.count < 1 || d.td.count > 256) return 0;  // depth taps are plain K items (feature_fuse's gradient: 128)
   if (d.Lh < 8 || d.Lw < 8) return 0;
   const bool big = big_ok(d) || w32_ok(d);
   const int64_t nb_h = (d.Lh + 2 * TH - 1) / (2 * TH), nb_w = (d.Lw + 2 * TW - 1) / (2 * TW);
@@ -928,6 +940,56 @@ int64_t wino_workspace_bytes(const rehr_gather_gemm_desc& d) {
   if (img * d.ldx1 >= (1ll << 32) - 64 || (d.x2 && img * d.ldx2 >= (1ll << 32) - 64)) return 0;
   if (nb_h * nb_w * d.Ld >= (1ll << 31) || d.Npad / 32 > 65535 || d.N > 65535) return 0;
   return need;
+}
+
+// Split-K parts of one layer (same operands; consecutive depth-tap ranges; one output slab each) in ONE launch of
+// the big-tile kernel.  REHR_OK launched; REHR_ENOSUP not applicable.
+int wino_conv_split_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t stream) {
+  if (count < 2 || count > 8) return REHR_ENOSUP;
+  const rehr_gather_gemm_desc& d0 = ds[0];
+  if (!big_ok(d0) || (int64_t)d0.N * count > 65535) return REHR_ENOSUP;
+  WinoParams p;
+  p.d = d0;
+  p.kchunks = (d0.Cin + 31) / 32;
+  p.dh0 = -1;
+  p.dw0 = -1;
+  p.up = nullptr;
+  p.up_bytes = 0;
+  p.nsplit = count;
+  for (int i = 0; i < count; ++i) {
+    const rehr_gather_gemm_desc& d = ds[i];
+    if (!d.wino_ws || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;
+    const int64_t need = wino_workspace_bytes(d);
+    if (need == 0 || d.wino_ws_bytes < need) return REHR_ENOSUP;
+    // the parts differ in the depth taps and the destination only; no epilogue work (the combine has it)
+    if (d.bias || d.stats_mode || d.act != REHR_ACT_NONE || d.x2 != d0.x2 || d.Cin != d0.Cin || d.c1 != d0.c1 ||
+        d.ldx1 != d0.ldx1 || d.ldx2 != d0.ldx2 || d.Cout != d0.Cout || d.ldy != d0.ldy || d.Ld != d0.Ld ||
+        d.Lh != d0.Lh || d.Lw != d0.Lw || d.Di != d0.Di || d.Hi != d0.Hi || d.Wi != d0.Wi || d.bd != d0.bd ||
+        d.bh != d0.bh || d.bw != d0.bw || d.KH != d0.KH || d.KW != d0.KW || d.th.count != d0.th.count ||
+        d.th.off0 != d0.th.off0 || d.th.offs != d0.th.offs || d.th.k0 != d0.th.k0 || d.th.ks != d0.th.ks ||
+        d.tw.count != d0.tw.count || d.tw.off0 != d0.tw.off0 || d.tw.offs != d0.tw.offs || d.tw.k0 != d0.tw.k0 ||
+        d.tw.ks != d0.tw.ks)
+      return REHR_ENOSUP;
+    p.s_td[i] = d.td;
+    p.s_up[i] = d.wino_ws;
+    p.s_up_bytes[i] = (uint32_t)need;
+    p.s_y[i] = d.y;
+  }
+  for (int i = 0; i < count; ++i) {
+    const int rc = wino_weights_frag_launch(ds[i], p.kchunks, stream);
+    if (rc != REHR_OK) return rc;
+  }
+  p.nb_h = (d0.Lh + 15) / 16;
+  p.nb_w = (d0.Lw + 15) / 16;
+  const size_t smem_x = (size_t)2 * BUF2 * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
+  const size_t smem = smem_x > smem_e ? smem_x : smem_e;
+  if (hipFuncSetAttribute((const void*)wino_conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+      hipSuccess)
+    return REHR_EHIP;
+  dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d0.Ld), d0.Npad / 64, d0.N * count);
+  hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
 }
 
 // REHR_OK launched; REHR_ENOSUP not applicable.
@@ -943,6 +1005,7 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   p.dw0 = -1;
   p.up = d.wino_ws;
   p.up_bytes = (uint32_t)need;
+  p.nsplit = 0;
   if (w32_ok(d) && !no_big) {
     const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
     int64_t blocks = (total + 255) / 256;

@@ -475,7 +475,7 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   if (off) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (!three_taps_w(d.th, d.bh) || !three_taps_w(d.tw, d.bw)) return false;
-  if (d.td.count < 1 || d.td.count > 3) return false;
+  if (d.td.count < 1 || d.td.count > 256) return false;  // any number of depth taps (feature_fuse: 128): one grid.z each
   if (d.Hg != d.Lh || d.Wg != d.Lw) return false;
   if (d.Ca < 16 || d.Cg < 16 || d.Ca % 4 || d.Cg % 4) return false;
   if (d.Lh < 4 || d.Lw < 6) return false;

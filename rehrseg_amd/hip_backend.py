@@ -156,6 +156,7 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             wino_launches += 1
             d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
+    _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
 
 
@@ -178,7 +179,10 @@ def gather_gemm_multi(calls):
     if len(calls) == 1:
         return gather_gemm(*calls[0])
     arr = (L.GatherGemmDesc * len(calls))()
-    flops = sum(_gg_desc(arr[i], *a) for i, a in enumerate(calls))
+    flops, keeps = 0.0, []  # every part keeps its own scratch alive: split-K parts run in ONE launch
+    for i, a in enumerate(calls):
+        flops += _gg_desc(arr[i], *a)
+        keeps.append(_gg_desc.last_keep)
     with _timed(_gg_family(arr[0]) if all(arr[i].wino_ws for i in range(len(calls))) else "gather_gemm", flops):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 

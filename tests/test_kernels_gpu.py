@@ -191,6 +191,22 @@ def test_split_k_many_depth_taps():
          lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, 1, (0, 1, 1)), 0.2), [x, w, b], [True, True, True])
 
 
+def test_split_k_many_depth_taps_winograd():
+    """The same contraction on a plane the Winograd kernels accept (32 x 32, 64 channels): the 8 tap-range parts
+    (4 depth taps each) run as ONE launch of the big-tile kernel, every part with its own transformed weights and
+    slab; the input gradient (one valid depth tap per output slice) and the weight gradient (32 depth taps = 32
+    grid.z slices) take the Winograd kernels too."""
+    from rehrseg_amd import hip_backend
+    x = _mk(1, 64, 32, 32, 32, seed=70)
+    w = _mk(64, 64, 32, 3, 3, seed=71) / (64 * 32 * 9) ** 0.5
+    b = _mk(64, seed=72)
+    before, before_w = hip_backend.wino_launches, hip_backend.wino_wgrad_launches
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, (0, 1, 1), act=ops.ACT_LRELU, slope=0.2),
+         lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, 1, (0, 1, 1)), 0.2), [x, w, b], [True, True, True])
+    assert hip_backend.wino_launches - before == 8 + 1      # 8 forward parts + the input gradient
+    assert hip_backend.wino_wgrad_launches - before_w == 1
+
+
 def test_split_k_low_resolution_stage_with_instnorm():
     """nnU-Net bottom stage (4^3 voxels, hundreds of channels): 6 tap ranges in one grid, the combine carries
     bias + InstanceNorm statistics; the input gradient takes the same route.  (8^3 stages go to the
