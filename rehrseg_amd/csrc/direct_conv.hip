@@ -3,6 +3,7 @@
 // for the HBM roofline: NDHWC, 16-byte stores, weights staged once per block in
 // LDS and read with wave-uniform (broadcast) addresses.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -836,6 +837,107 @@ __global__ __launch_bounds__(256) void small_cout_wgrad_halo_kernel(const rehr_d
   }
 }
 
+// ---- the same brick, register-blocked over the row taps (2 output channels, KW = 5, <= 128 (kd, kh, quad)
+// triples: sr_head's 5x5x5 16->2).  A thread owns ALL KW taps of one (kd, kh, channel quad) for one of the two
+// brick slices: per brick row it reads the 12 x voxels and the 8 dY pairs once and forms 5 x 8 x 4 packed
+// FMAs ({x, x} * {dy0, dy1}) -- 3.3x fewer LDS reads per FMA than one (tap, quad) pair per thread, which was LDS
+// bound at a quarter of the vector rate.  LDS rows are padded by 16 floats so that the lanes of a wave
+// ((kd, kh) neighbours x 4 quads) hit distinct banks.
+template <int KW>
+__global__ __launch_bounds__(256) void small_cout2_wgrad_rows_kernel(const rehr_direct_conv_desc d,
+                                                                     float* __restrict__ slab, int bricks_per_block,
+                                                                     int nb_d, int nb_h, int nb_w) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float hl[];
+  const int HD = HB_D + d.KD - 1, HH = HB_H + d.KH - 1;
+  constexpr int HW = HB_W + KW - 1;
+  const int RS = HW * d.Cin + 16;         // floats per (hd, hh) row of the x halo
+  const int nrows = HD * HH;
+  float* xs = hl;                         // [nrows][RS]
+  float* ys = hl + nrows * RS;            // [HB_VOX][2]
+  const int c4n = d.Cin / 4, ntrip = d.KD * d.KH * c4n;
+  const int trip = threadIdx.x >> 1, half = threadIdx.x & 1;   // neighbouring lanes: the two brick slices
+  const bool has = trip < ntrip;
+  const int tq = has ? trip : 0;
+  const int quad = tq % c4n, kh = (tq / c4n) % d.KH, kd = tq / (c4n * d.KH);
+  f32x2_ acc[KW][4];
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[k][e] = f32x2_{0.f, 0.f};
+  const int64_t nbricks = (int64_t)d.N * nb_d * nb_h * nb_w;
+  const int64_t b0 = (int64_t)blockIdx.x * bricks_per_block;
+  for (int bi = 0; bi < bricks_per_block; ++bi) {
+    const int64_t br = b0 + bi;
+    if (br >= nbricks) break;
+    const int bw = (int)(br % nb_w);
+    int64_t r = br / nb_w;
+    const int bh = (int)(r % nb_h); r /= nb_h;
+    const int bd = (int)(r % nb_d);
+    const int n = (int)(r / nb_d);
+    const int od0 = bd * HB_D, oh0 = bh * HB_H, ow0 = bw * HB_W;
+    __syncthreads();  // previous brick fully consumed
+    const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
+    for (int i = threadIdx.x; i < nrows * HW * c4n; i += 256) {
+      const int q = i % c4n, hv = i / c4n;
+      const int hw_ = hv % HW, row = hv / HW;
+      const int hh_ = row % HH, hd_ = row / HH;
+      const int id = od0 - d.pd + hd_, ih = oh0 - d.ph + hh_, iw = ow0 - d.pw + hw_;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi && (unsigned)iw < (unsigned)d.Wi)
+        v = *reinterpret_cast<const f32x4*>(xn + (((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx + q * 4);
+      *reinterpret_cast<f32x4*>(xs + row * RS + hw_ * d.Cin + q * 4) = v;
+    }
+    for (int i = threadIdx.x; i < HB_VOX * 2; i += 256) {
+      const int c = i & 1, v = i >> 1;
+      const int vw = v % HB_W, vh = (v / HB_W) % HB_H, vd = v / (HB_W * HB_H);
+      const int od = od0 + vd, oh = oh0 + vh, ow = ow0 + vw;
+      float val = 0.f;
+      if (c < d.Cout && od < d.Do && oh < d.Ho && ow < d.Wo)
+        val = d.y[((((int64_t)n * d.Do + od) * d.Ho + oh) * d.Wo + ow) * d.ldy + c];
+      ys[i] = val;
+    }
+    __syncthreads();
+    if (has) {
+      const float* xb = xs + ((kd + half) * HH + kh) * RS + quad * 4;
+      const float* yb = ys + half * HB_H * HB_W * 2;
+#pragma unroll 2
+      for (int vh = 0; vh < HB_H; ++vh) {
+        f32x4 xv[HW];
+#pragma unroll
+        for (int j = 0; j < HW; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xb + vh * RS + j * d.Cin);
+        f32x4 dq[HB_W / 2];  // dY pairs of the 8 voxels of this row
+#pragma unroll
+        for (int j = 0; j < HB_W / 2; ++j) dq[j] = *reinterpret_cast<const f32x4*>(yb + vh * HB_W * 2 + j * 4);
+#pragma unroll
+        for (int v = 0; v < HB_W; ++v) {
+          const f32x2_ dy2 = {dq[v >> 1][(v & 1) * 2], dq[v >> 1][(v & 1) * 2 + 1]};
+#pragma unroll
+          for (int k = 0; k < KW; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[k][e] = __builtin_elementwise_fma(f32x2_{xv[v + k][e], xv[v + k][e]}, dy2, acc[k][e]);
+        }
+      }
+    }
+  }
+  // the two slices of a triple are neighbouring lanes: one shuffle, the even lane stores
+  const int T = d.KD * d.KH * KW;
+  float* sb = slab + (int64_t)blockIdx.x * d.Cout * d.Cin * T;
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = acc[k][e][0] + __shfl_xor(acc[k][e][0], 1, 64);
+      const float a1 = acc[k][e][1] + __shfl_xor(acc[k][e][1], 1, 64);
+      if (has && half == 0) {
+        const int t = (kd * d.KH + kh) * KW + k;
+        sb[((int64_t)0 * d.Cin + quad * 4 + e) * T + t] = a0;
+        if (d.Cout > 1) sb[((int64_t)1 * d.Cin + quad * 4 + e) * T + t] = a1;
+      }
+    }
+}
+
 // partial[b][c] = sum over the block's voxels of dy[.][c]
 __global__ __launch_bounds__(256) void thin_bias_partial_kernel(const float* __restrict__ dy, int ld, int C,
                                                                 int64_t rows, float* __restrict__ partial) {
@@ -991,7 +1093,16 @@ extern "C" int rehr_conv_small_cout_wgrad_f32(const rehr_direct_conv_desc* dp, f
     const int hblocks = sc_halo_blocks(d, &bpb, &nbd, &nbh, &nbw);
     const int64_t hv = (int64_t)(HB_D + d.KD - 1) * (HB_H + d.KH - 1) * (HB_W + d.KW - 1);
     const size_t hsmem = (size_t)(hv * d.Cin + HB_VOX * CO) * sizeof(float);
-    if (CO == 2)
+    const int64_t rows_floats = (int64_t)(HB_D + d.KD - 1) * (HB_H + d.KH - 1) * ((HB_W + 4) * d.Cin + 16) + HB_VOX * 2;
+    if (CO == 2 && d.KW == 5 && d.KD * d.KH * (d.Cin / 4) <= 128 && rows_floats * 4 <= 64 * 1024) {
+      static const bool old_kernel = getenv("REHR_THIN_WGRAD_OLD") != nullptr;  // A/B switch for benchmarking
+      if (!old_kernel) {
+        hipLaunchKernelGGL(small_cout2_wgrad_rows_kernel<5>, dim3(hblocks), dim3(256), (size_t)rows_floats * 4, st, d,
+                           workspace, bpb, nbd, nbh, nbw);
+      } else
+        hipLaunchKernelGGL(small_cout_wgrad_halo_kernel<2>, dim3(hblocks), dim3(256), hsmem, st, d, workspace, bpb, nbd,
+                           nbh, nbw);
+    } else if (CO == 2)
       hipLaunchKernelGGL(small_cout_wgrad_halo_kernel<2>, dim3(hblocks), dim3(256), hsmem, st, d, workspace, bpb, nbd,
                          nbh, nbw);
     else

@@ -32,3 +32,11 @@ xs = x[:1, :, :12, :20, :24].contiguous(memory_format=torch.channels_last_3d)
 ys, _ = ops.conv_forward(xs, None, w, b, cfg, 0, 0.0, 0)
 ref = torch.nn.functional.conv3d(xs.cpu().double(), w.cpu().double(), b.cpu().double(), 1, K // 2)
 print("fwd err", ((ys.cpu().double() - ref).abs().max() / ref.abs().max()).item())
+dys = torch.randn_like(ys)
+xr = xs.cpu().double().requires_grad_(True); wr = w.cpu().double().requires_grad_(True); br = b.cpu().double().requires_grad_(True)
+torch.nn.functional.conv3d(xr, wr, br, 1, K // 2).backward(dys.cpu().double())
+dws, dbs = ops.conv_wgrad(dys, xs, None, w, cfg, True)
+dxs, _ = ops.conv_dgrad(dys, w, (12, 20, 24), Cin, 0, cfg)
+print("wgrad err", ((dws.cpu().double() - wr.grad).abs().max() / wr.grad.abs().max()).item(),
+      "bias", ((dbs.cpu().double() - br.grad).abs().max() / br.grad.abs().max()).item(),
+      "dgrad err", ((dxs.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max()).item())
