@@ -349,7 +349,7 @@ extern "C" int rehr_im2col_f32(const rehr_direct_conv_desc* dp, float* out, int3
 // taps over it, with the weights of that (kd,kh) broadcast from LDS.
 namespace {
 
-constexpr int SC_VOX = 4;     // voxels per thread along W
+constexpr int SC_VOX = 8;     // voxels per thread along W
 constexpr int SC_MAXKW = 7;
 constexpr int SC_BIAS_BLOCKS = 1024;
 
