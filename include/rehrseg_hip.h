@@ -280,6 +280,21 @@ int rehr_upsample_depth_bwd_f32(const float* dy, float* dx, int32_t N,
                                 int32_t Di, int32_t Do, int64_t HW, int32_t C,
                                 void* stream);
 
+/* Depth upsample fused with the depth-tap sum of the convolution that follows it
+ * (models/seg_model.py:204-205: F.interpolate(features, (upscale,1,1), trilinear, align_corners) ->
+ * sr_head[0] = Conv3d(32, 16, 3, padding=1) -> ReLU).  Both are linear, so the (kH,kW) part of every
+ * depth tap kd is taken on the low-resolution slices first -- g[n][j][hw][kd*C + co], a (1,kH,kW)
+ * convolution with KD*C output channels on the ordinary conv path -- and
+ *   y[n][d][hw][co] = act(bias[co] + sum_kd [0 <= u < Do] ((1-t) g[n][i0][hw][kd*C+co] + t g[n][i1][..])),
+ *   u = d + kd - pd, (i0, i1, t) = align_corners source of upsampled slice u.
+ * bwd: dg from dz = dy * act'(y) (rehr_act_bwd_f32).  C % 4 == 0.                                */
+int rehr_upmix_depth_fwd_f32(const float* g, const float* bias, float* y, int32_t N,
+                             int32_t Di, int32_t Do, int64_t HW, int32_t C, int32_t KD,
+                             int32_t pd, int32_t act, float slope, void* stream);
+int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, int32_t Di,
+                             int32_t Do, int64_t HW, int32_t C, int32_t KD, int32_t pd,
+                             void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Fused segmentation loss: softmax + cross-entropy, optionally
  * weighted by the uncertainty map with the reference's (B,D,H,W)*(B,1,D,H,W)

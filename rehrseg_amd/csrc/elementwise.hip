@@ -374,6 +374,80 @@ __global__ void upsample_depth_bwd_kernel(const float* __restrict__ dy, float* _
   }
 }
 
+// ---------------------------------------------------------------- depth upsample fused with a depth-tap sum
+// y = act(b + conv3x3x3(upsample_depth(f)))  (models/seg_model.py:204-205, sr_head.0 on the 4x upsampled features)
+// is linear in f, so the 3x3 part of every depth tap is taken on the LOW-resolution slices first,
+//   G[n][j][hw][kd*C + co] = sum_{ci,kh,kw} f[n][j][..][ci] w[co][ci][kd][kh][kw]      (a (1,3,3) conv, KD*C outputs)
+// and this kernel interpolates and sums the taps:
+//   y[n][d][hw][co] = act(b[co] + sum_kd [0 <= d+kd-p < Do] ((1-t) G[n][i0][hw][kd*C+co] + t G[n][i1][hw][kd*C+co]))
+// with (i0, i1, t) the align_corners source of upsampled slice d+kd-p.  upscale x fewer multiplications, and the
+// upscale x larger feature tensor never exists.
+__global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float* __restrict__ bias,
+                                       float* __restrict__ y, int N, int Di, int Do, int64_t HW, int C, int KD,
+                                       int pd, int act, float slope) {
+  const int cq = C / 4;
+  const int64_t plane = HW * cq;  // float4 of y per depth slice
+  const int64_t total = (int64_t)N * Do * plane;
+  const int64_t gplane = HW * KD * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % plane;
+    const int64_t r = i / plane;
+    const int od = (int)(r % Do), n = (int)(r / Do);
+    const int q = (int)(p % cq);
+    const int64_t hw = p / cq;
+    f32x4 s = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kd = 0; kd < KD; ++kd) {
+      const int ud = od + kd - pd;  // slice of the (virtual) upsampled tensor
+      if ((unsigned)ud >= (unsigned)Do) continue;
+      int i0, i1;
+      float w1;
+      depth_src(ud, Di, Do, i0, i1, w1);
+      const int64_t off = hw * KD * cq + (int64_t)kd * cq + q;
+      const f32x4 a = reinterpret_cast<const f32x4*>(g)[((int64_t)n * Di + i0) * gplane + off];
+      const f32x4 b = reinterpret_cast<const f32x4*>(g)[((int64_t)n * Di + i1) * gplane + off];
+      s += a * (1.f - w1) + b * w1;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = apply_act(s[e], act, slope);
+    reinterpret_cast<f32x4*>(y)[i] = s;
+  }
+}
+// dG[n][j][hw][kd*C+co] = sum over upsampled slices ud with source j of coef(ud, j) * dz[n][ud - kd + p][hw][co]
+__global__ void upmix_depth_bwd_kernel(const float* __restrict__ dz, float* __restrict__ dg, int N, int Di, int Do,
+                                       int64_t HW, int C, int KD, int pd) {
+  const int cq = C / 4;
+  const int64_t gplane = HW * KD * cq;
+  const int64_t plane = HW * cq;
+  const int64_t total = (int64_t)N * Di * gplane;
+  const float inv = (Di > 1) ? (float)(Do - 1) / (float)(Di - 1) : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % gplane;
+    const int64_t r = i / gplane;
+    const int id = (int)(r % Di), n = (int)(r / Di);
+    const int q = (int)(p % cq);
+    const int kd = (int)((p / cq) % KD);
+    const int64_t hw = p / ((int64_t)cq * KD);
+    int lo = (int)floorf((float)(id - 1) * inv) - 1, hi = (int)ceilf((float)(id + 1) * inv) + 1;
+    if (lo < 0 || Di == 1) lo = 0;
+    if (hi > Do - 1 || Di == 1) hi = Do - 1;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int ud = lo; ud <= hi; ++ud) {
+      const int od = ud - kd + pd;
+      if ((unsigned)od >= (unsigned)Do) continue;
+      int i0, i1;
+      float w1;
+      depth_src(ud, Di, Do, i0, i1, w1);
+      float wgt = 0.f;
+      if (i0 == id) wgt += 1.f - w1;
+      if (i1 == id) wgt += w1;
+      if (wgt != 0.f) s += reinterpret_cast<const f32x4*>(dz)[((int64_t)n * Do + od) * plane + hw * cq + q] * wgt;
+    }
+    reinterpret_cast<f32x4*>(dg)[i] = s;
+  }
+}
+
 // ---------------------------------------------------------------- misc
 __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
                                int act, float slope) {
@@ -619,6 +693,30 @@ extern "C" int rehr_upsample_depth_bwd_f32(const float* dy, float* dx, int32_t N
   const int64_t total = (int64_t)N * Di * HW * C / 4;
   hipLaunchKernelGGL(upsample_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dy, dx,
                      N, Di, Do, HW, C);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_upmix_depth_fwd_f32(const float* g, const float* bias, float* y, int32_t N, int32_t Di, int32_t Do,
+                                        int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
+                                        void* stream) {
+  if (!g || !y || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || KD < 1 || pd < 0 || pd >= KD ||
+      !aligned16(g) || !aligned16(y) || (bias && !aligned16(bias)))
+    return REHR_EINVAL;
+  const int64_t total = (int64_t)N * Do * HW * C / 4;
+  hipLaunchKernelGGL(upmix_depth_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g, bias, y, N, Di, Do,
+                     HW, C, KD, pd, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+extern "C" int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, int32_t Di, int32_t Do, int64_t HW,
+                                        int32_t C, int32_t KD, int32_t pd, void* stream) {
+  if (!dz || !dg || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || KD < 1 || pd < 0 || pd >= KD ||
+      !aligned16(dz) || !aligned16(dg))
+    return REHR_EINVAL;
+  const int64_t total = (int64_t)N * Di * HW * KD * C / 4;
+  hipLaunchKernelGGL(upmix_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dz, dg, N, Di, Do, HW,
+                     C, KD, pd);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

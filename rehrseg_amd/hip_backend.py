@@ -405,6 +405,25 @@ def upsample_depth_bwd(dy, Di):
     return dx
 
 
+def upmix_depth_fwd(g, bias, Do, Cc, KD, pd, act, slope):
+    """g (N, KD*Cc, Di, H, W) NDHWC -> y (N, Cc, Do, H, W): depth interpolation + depth-tap sum + bias + act."""
+    _chk_dev(g, bias)
+    N, _, Di, H, W = g.shape
+    y = new_act(N, Cc, Do, H, W, like=g)
+    L.check(L.load().rehr_upmix_depth_fwd_f32(_ptr(g), _ptr(bias), _ptr(y), N, Di, Do, H * W, Cc, KD, pd, act, slope,
+                                              _stream()), "rehr_upmix_depth_fwd_f32")
+    return y
+
+
+def upmix_depth_bwd(dz, Di, KD, pd):
+    _chk_dev(dz)
+    N, Cc, Do, H, W = dz.shape
+    dg = new_act(N, KD * Cc, Di, H, W, like=dz)
+    L.check(L.load().rehr_upmix_depth_bwd_f32(_ptr(dz), _ptr(dg), N, Di, Do, H * W, Cc, KD, pd, _stream()),
+            "rehr_upmix_depth_bwd_f32")
+    return dg
+
+
 def act_fwd(x, act, slope):
     _chk_dev(x)
     y = torch.empty_like(x)

@@ -218,9 +218,10 @@ class SegModel(PlainConvUNet):
     def forward(self, x, return_inetermediate_feature=False):
         skips = self.encoder(x)
         out, features = self.decoder(skips)
-        out_up = ops.upsample_depth(features, self.upscale)
         h0, h2 = self.sr_head[0], self.sr_head[2]
-        out_up = ops.fused_conv3d(out_up, h0.weight, h0.bias, 1, 1, act=ops.ACT_RELU)
+        # F.interpolate(features, (upscale,1,1), trilinear, align_corners=True) -> sr_head[0] -> ReLU (ref :204-205):
+        # the 3x3 part of every depth tap on the LOW-resolution features, then interpolate + sum the taps
+        out_up = ops.upsample_conv3d_depth(features, h0.weight, h0.bias, self.upscale, act=ops.ACT_RELU)
         out_up = ops.fused_conv3d(out_up, h2.weight, h2.bias, 1, 2)
         if return_inetermediate_feature:
             return out, out_up, skips

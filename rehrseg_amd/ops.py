@@ -495,6 +495,42 @@ class _UpsampleDepth(torch.autograd.Function):
         return get_backend().upsample_depth_bwd(to_cl(dy), ctx.Di), None
 
 
+class _UpMixDepth(torch.autograd.Function):
+    """y = act(bias + sum over depth taps of the depth-interpolated per-tap responses g) -- see rehr_upmix_depth_fwd_f32."""
+
+    @staticmethod
+    def forward(ctx, g, bias, Do, Cc, KD, pd, act, slope):
+        g = to_cl(g)
+        y = get_backend().upmix_depth_fwd(g, bias, Do, Cc, KD, pd, act, slope)
+        ctx.save_for_backward(y)
+        ctx.cfg = (g.shape[2], KD, pd, act, slope, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        Di, KD, pd, act, slope, has_bias = ctx.cfg
+        be = get_backend()
+        dz = to_cl(dy) if act == ACT_NONE else be.act_bwd(to_cl(dy), y, act, slope)
+        db = be.channel_sum(dz) if (has_bias and ctx.needs_input_grad[1]) else None
+        return be.upmix_depth_bwd(dz, Di, KD, pd), db, None, None, None, None, None, None
+
+
+def upsample_conv3d_depth(x, w, b, scale, act=ACT_NONE, slope=0.0):
+    """conv3d(upsample_depth(x, scale), w, b, stride 1, 'same' padding) + activation without the upsampled tensor
+    (models/seg_model.py:204-205).  Interpolation along depth and the convolution are both linear: the (kH,kW) part
+    of every depth tap runs on the low-resolution slices -- one (1,kH,kW) conv with KD*Cout output channels, scale x
+    fewer multiplications -- and one HBM-bound pass interpolates and sums the depth taps.  Same result up to fp32
+    reassociation."""
+    Cout, Cin, KD, KH, KW = w.shape
+    if KD % 2 == 0 or KH % 2 == 0 or KW % 2 == 0 or Cout % 4:
+        raise NotImplementedError("upsample_conv3d_depth: odd kernel extents and Cout % 4 == 0")
+    Do = int(x.shape[2] * scale)
+    wg = w.permute(2, 0, 1, 3, 4).reshape(KD * Cout, Cin, 1, KH, KW)  # row kd*Cout + co
+    g = fused_conv3d(x, wg, None, 1, (0, KH // 2, KW // 2))
+    return _UpMixDepth.apply(g, b, Do, Cout, KD, KD // 2, int(act), float(slope))
+
+
 def upsample_depth(x, scale):
     """Linear interpolation along depth only, align_corners=True (seg_model.py:204)."""
     Do = int(x.shape[2] * scale)

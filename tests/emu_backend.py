@@ -254,6 +254,34 @@ def upsample_depth_bwd(dy, Di):
     return torch.einsum("od,ncohw->ncdhw", Wm, dy).contiguous(memory_format=torch.channels_last_3d)
 
 
+def _upmix_w(Di, Do, KD, pd, dtype):
+    """M[kd][od][j]: coefficient of low-resolution slice j in output slice od through depth tap kd."""
+    Wm = _depth_w(Di, Do, dtype)  # [ud][j]
+    M = torch.zeros((KD, Do, Di), dtype=dtype)
+    for kd in range(KD):
+        for od in range(Do):
+            ud = od + kd - pd
+            if 0 <= ud < Do:
+                M[kd, od] = Wm[ud]
+    return M
+
+
+def upmix_depth_fwd(g, bias, Do, Cc, KD, pd, act, slope):
+    N, _, Di, H, W = g.shape
+    M = _upmix_w(Di, Do, KD, pd, g.dtype)
+    y = torch.einsum("koj,nkcjhw->ncohw", M, g.reshape(N, KD, Cc, Di, H, W))
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1, 1)
+    return _act(y, act, slope).contiguous(memory_format=torch.channels_last_3d)
+
+
+def upmix_depth_bwd(dz, Di, KD, pd):
+    N, Cc, Do, H, W = dz.shape
+    M = _upmix_w(Di, Do, KD, pd, dz.dtype)
+    dg = torch.einsum("koj,ncohw->nkcjhw", M, dz).reshape(N, KD * Cc, Di, H, W)
+    return dg.contiguous(memory_format=torch.channels_last_3d)
+
+
 def act_fwd(x, act, slope):
     return _act(x, act, slope)
 

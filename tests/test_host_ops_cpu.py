@@ -158,6 +158,21 @@ def test_upsample_depth(emu, Di, scale):
     _cmp(torch.autograd.grad(y, x, g)[0], torch.autograd.grad(ref, x, g)[0], 1e-6)
 
 
+@pytest.mark.parametrize("Di,scale,K", [(5, 4, (3, 3, 3)), (1, 3, (3, 3, 3)), (6, 2, (5, 3, 3))])
+def test_upsample_conv3d_depth(emu, Di, scale, K):
+    """interpolate -> conv -> ReLU (ref models/seg_model.py:204-205) as low-resolution (1,kH,kW) conv + tap mixing."""
+    x = _rand(2, 32, Di, 5, 6).requires_grad_()
+    w = (_rand(16, 32, *K) / (32 * K[0] * K[1] * K[2]) ** 0.5).requires_grad_()
+    b = _rand(16).requires_grad_()
+    y = ops.upsample_conv3d_depth(x, w, b, scale, act=ops.ACT_RELU)
+    up = F.interpolate(x, scale_factor=(scale, 1, 1), mode="trilinear", align_corners=True)
+    ref = F.relu(F.conv3d(up, w, b, 1, tuple(k // 2 for k in K)))
+    _cmp(y, ref, 1e-5)
+    g = torch.randn_like(ref)
+    for a, e in zip(torch.autograd.grad(y, [x, w, b], g), torch.autograd.grad(ref, [x, w, b], g)):
+        _cmp(a, e, 1e-5)
+
+
 @pytest.mark.parametrize("Cin,Cout,K,pad", [(32, 2, (1, 1, 1), 0), (16, 2, (5, 5, 5), 2), (32, 16, (3, 3, 3), 1),
                                             (64, 4, (1, 7, 7), (0, 3, 3))])
 def test_thin_output_and_half_chunk_convs(emu, Cin, Cout, K, pad):

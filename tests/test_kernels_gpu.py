@@ -367,6 +367,20 @@ def test_upsample_depth(Di, scale):
          lambda x: F.interpolate(x, scale_factor=(scale, 1, 1), mode="trilinear", align_corners=True), [x], [True])
 
 
+@pytest.mark.parametrize("Di,scale,K", [(5, 4, (3, 3, 3)), (7, 2, (3, 3, 3)), (1, 3, (3, 3, 3)), (6, 4, (5, 3, 3))])
+def test_upsample_conv3d_depth(Di, scale, K):
+    """sr_head.0 on the depth-upsampled features (ref models/seg_model.py:204-205) without the upsampled tensor:
+    (1,3,3) conv on the low-resolution slices + interpolate-and-sum-the-depth-taps, against interpolate -> conv -> ReLU."""
+    x = _mk(2, 32, Di, 10, 12, seed=33)
+    w = _mk(16, 32, *K, seed=34) / (32 * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(16, seed=35)
+    pad = tuple(k // 2 for k in K)
+    _run(lambda x, w, b: ops.upsample_conv3d_depth(x, w, b, scale, act=ops.ACT_RELU),
+         lambda x, w, b: F.relu(F.conv3d(F.interpolate(x, scale_factor=(scale, 1, 1), mode="trilinear",
+                                                       align_corners=True), w, b, 1, pad)),
+         [x, w, b], [True, True, True])
+
+
 def test_rejects_cpu_tensors():
     from rehrseg_amd.lib import RehrsegHipError
     with pytest.raises(RehrsegHipError):
