@@ -382,35 +382,58 @@ __global__ void upsample_depth_bwd_kernel(const float* __restrict__ dy, float* _
 //   y[n][d][hw][co] = act(b[co] + sum_kd [0 <= d+kd-p < Do] ((1-t) G[n][i0][hw][kd*C+co] + t G[n][i1][hw][kd*C+co]))
 // with (i0, i1, t) the align_corners source of upsampled slice d+kd-p.  upscale x fewer multiplications, and the
 // upscale x larger feature tensor never exists.
+// A thread walks UPMIX_RUN consecutive output slices of one (sample, voxel, channel quad) column and keeps the two
+// source slices of every depth tap in registers: they change once per `upscale` steps, so g is read ~once.
+constexpr int UPMIX_RUN = 16, UPMIX_MAXKD = 5;
 __global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float* __restrict__ bias,
                                        float* __restrict__ y, int N, int Di, int Do, int64_t HW, int C, int KD,
                                        int pd, int act, float slope) {
   const int cq = C / 4;
   const int64_t plane = HW * cq;  // float4 of y per depth slice
-  const int64_t total = (int64_t)N * Do * plane;
+  const int runs = (Do + UPMIX_RUN - 1) / UPMIX_RUN;
+  const int64_t total = (int64_t)N * runs * plane;
   const int64_t gplane = HW * KD * cq;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i % plane;
     const int64_t r = i / plane;
-    const int od = (int)(r % Do), n = (int)(r / Do);
+    const int run = (int)(r % runs), n = (int)(r / runs);
     const int q = (int)(p % cq);
     const int64_t hw = p / cq;
-    f32x4 s = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kd = 0; kd < KD; ++kd) {
-      const int ud = od + kd - pd;  // slice of the (virtual) upsampled tensor
-      if ((unsigned)ud >= (unsigned)Do) continue;
-      int i0, i1;
-      float w1;
-      depth_src(ud, Di, Do, i0, i1, w1);
-      const int64_t off = hw * KD * cq + (int64_t)kd * cq + q;
-      const f32x4 a = reinterpret_cast<const f32x4*>(g)[((int64_t)n * Di + i0) * gplane + off];
-      const f32x4 b = reinterpret_cast<const f32x4*>(g)[((int64_t)n * Di + i1) * gplane + off];
-      s += a * (1.f - w1) + b * w1;
-    }
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4* gn = reinterpret_cast<const f32x4*>(g) + (int64_t)n * Di * gplane + hw * KD * cq + q;
+    int c0[UPMIX_MAXKD], c1[UPMIX_MAXKD];  // cached source slices per depth tap
+    f32x4 v0[UPMIX_MAXKD], v1[UPMIX_MAXKD];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] = apply_act(s[e], act, slope);
-    reinterpret_cast<f32x4*>(y)[i] = s;
+    for (int kd = 0; kd < UPMIX_MAXKD; ++kd) { c0[kd] = -1; c1[kd] = -1; v0[kd] = bv; v1[kd] = bv; }
+    const int od_end = min(Do, (run + 1) * UPMIX_RUN);
+    for (int od = run * UPMIX_RUN; od < od_end; ++od) {
+      f32x4 s = bv;
+#pragma unroll
+      for (int kd = 0; kd < UPMIX_MAXKD; ++kd) {
+        if (kd < KD) {
+          const int ud = od + kd - pd;  // slice of the (virtual) upsampled tensor
+          if ((unsigned)ud < (unsigned)Do) {
+            int i0, i1;
+            float w1;
+            depth_src(ud, Di, Do, i0, i1, w1);
+            if (i0 != c0[kd]) {
+              if (i0 == c1[kd]) v0[kd] = v1[kd];  // the interval moved up by one slice
+              else v0[kd] = gn[(int64_t)i0 * gplane + kd * cq];
+              c0[kd] = i0;
+            }
+            if (i1 != c1[kd]) {
+              v1[kd] = (i1 == i0) ? v0[kd] : gn[(int64_t)i1 * gplane + kd * cq];
+              c1[kd] = i1;
+            }
+            s += v0[kd] * (1.f - w1) + v1[kd] * w1;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = apply_act(s[e], act, slope);
+      reinterpret_cast<f32x4*>(y)[((int64_t)n * Do + od) * plane + p] = s;
+    }
   }
 }
 // dG[n][j][hw][kd*C+co] = sum over upsampled slices ud with source j of coef(ud, j) * dz[n][ud - kd + p][hw][co]
@@ -701,9 +724,9 @@ extern "C" int rehr_upmix_depth_fwd_f32(const float* g, const float* bias, float
                                         int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
                                         void* stream) {
   if (!g || !y || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || KD < 1 || pd < 0 || pd >= KD ||
-      !aligned16(g) || !aligned16(y) || (bias && !aligned16(bias)))
+      !aligned16(g) || !aligned16(y) || (bias && !aligned16(bias)) || KD > UPMIX_MAXKD)
     return REHR_EINVAL;
-  const int64_t total = (int64_t)N * Do * HW * C / 4;
+  const int64_t total = (int64_t)N * ((Do + UPMIX_RUN - 1) / UPMIX_RUN) * HW * C / 4;
   hipLaunchKernelGGL(upmix_depth_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g, bias, y, N, Di, Do,
                      HW, C, KD, pd, act, slope);
   REHR_LAUNCH_CHECK();
