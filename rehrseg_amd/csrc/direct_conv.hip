@@ -438,6 +438,9 @@ __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(const rehr_direct
   __syncthreads();
   const int wg = (d.Wi + SC_VOX - 1) / SC_VOX;
   const int c16n = d.Cin / 16;
+  // (SC_VOX is even, so a thread's first column iw0 + pw - (KW-1) is even iff pw - (KW-1) is)
+  const bool pairs16 = d.ldy == 2 && d.Cout == 2 && !(d.Wo & 1) && !((d.pw - (d.KW - 1)) & 1) &&
+                       !((uintptr_t)d.y & 15);
   const int64_t groups = (int64_t)d.N * d.Di * d.Hi * wg * c16n;
   for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
     const int gw = (int)(gidx % wg);
@@ -463,12 +466,31 @@ __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(const rehr_direct
         const float* wr = wl + (kd * d.KH + kh) * d.KW * CO * d.Cin;
         // dy row segment: positions iw0 + p - (KW-1) .. iw0 + p + SC_VOX - 1
         float seg[SC_VOX + SC_MAXKW - 1][CO];
+        const int ow_first = iw0 + d.pw - (d.KW - 1);
+        if (CO == 2 && pairs16) {
+          // two-channel dY rows are contiguous: the thread's segment in 16-byte loads (two voxels each; the
+          // segment starts on an even column and Wo is even, so a pair is inside or outside as a whole),
+          // clamped address + select instead of a branch
 #pragma unroll
-        for (int j = 0; j < SC_VOX + SC_MAXKW - 1; ++j) {
-          const int ow = iw0 + d.pw - (d.KW - 1) + j;
-          const bool ok = j < SC_VOX + d.KW - 1 && (unsigned)ow < (unsigned)d.Wo;
+          for (int j = 0; j < SC_VOX + SC_MAXKW - 1; j += 2) {
+            const int ow = ow_first + j;
+            const bool ok = (j < SC_VOX + d.KW - 1) & ((unsigned)ow < (unsigned)d.Wo);
+            const f32x4 ld = *reinterpret_cast<const f32x4*>(yr + (int64_t)(ok ? ow : 0) * 2);
+            seg[j][0] = ok ? ld[0] : 0.f;
+            seg[j][1] = ok ? ld[1] : 0.f;
+            if (j + 1 < SC_VOX + SC_MAXKW - 1) {
+              seg[j + 1][0] = ok ? ld[2] : 0.f;
+              seg[j + 1][1] = ok ? ld[3] : 0.f;
+            }
+          }
+        } else {
 #pragma unroll
-          for (int c = 0; c < CO; ++c) seg[j][c] = (ok && c < d.Cout) ? yr[(int64_t)ow * d.ldy + c] : 0.f;
+          for (int j = 0; j < SC_VOX + SC_MAXKW - 1; ++j) {
+            const int ow = ow_first + j;
+            const bool ok = j < SC_VOX + d.KW - 1 && (unsigned)ow < (unsigned)d.Wo;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) seg[j][c] = (ok && c < d.Cout) ? yr[(int64_t)ow * d.ldy + c] : 0.f;
+          }
         }
 #pragma unroll
         for (int kw = 0; kw < SC_MAXKW; ++kw) {
