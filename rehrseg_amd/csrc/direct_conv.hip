@@ -859,6 +859,51 @@ __global__ __launch_bounds__(256) void small_cout_wgrad_halo_kernel(const rehr_d
   }
 }
 
+// Brick staging for the two kernels below: the 16-byte pieces of the x halo of a brick are fetched into registers
+// (all loads in flight at once -- a load -> LDS store loop pays one memory round trip per piece) and stored to
+// LDS one iteration later, so the fetch of the NEXT brick overlaps the sweep of the current one.
+constexpr int BRK_MAXP = 14;  // pieces per thread: 6 x 12 rows x 12 columns x 4 quads / 256 threads = 13.5
+// (extents are template constants: the piece -> (row, column, quad) maps are divisions by 4 and 12, not by runtime values)
+template <int HH_, int HWC_, int C4N_> struct BrickGeom { static constexpr int HH = HH_, HWc = HWC_, c4n = C4N_; int RS, npieces; };
+template <typename G>
+__device__ __forceinline__ void brick_fetch(const rehr_direct_conv_desc& d, const G& g, int64_t br,
+                                            int64_t nbricks, int nb_d, int nb_h, int nb_w, f32x4 (&tmp)[BRK_MAXP]) {
+  const bool live = br < nbricks;
+  const int64_t b = live ? br : 0;
+  const int bw = (int)(b % nb_w);
+  int64_t r = b / nb_w;
+  const int bh = (int)(r % nb_h); r /= nb_h;
+  const int bd = (int)(r % nb_d);
+  const int n = (int)(r / nb_d);
+  const int od0 = bd * HB_D, oh0 = bh * HB_H, ow0 = bw * HB_W;
+  const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
+#pragma unroll
+  for (int k = 0; k < BRK_MAXP; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const int q = i % g.c4n, hv = i / g.c4n;
+    const int hw_ = hv % g.HWc, row = hv / g.HWc;
+    const int hh_ = row % g.HH, hd_ = row / g.HH;
+    const int id = od0 - d.pd + hd_, ih = oh0 - d.ph + hh_, iw = ow0 - d.pw + hw_;
+    const bool ok = live & (i < g.npieces) & ((unsigned)id < (unsigned)d.Di) & ((unsigned)ih < (unsigned)d.Hi) &
+                    ((unsigned)iw < (unsigned)d.Wi);
+    const int64_t off = ok ? (((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx + q * 4 : 0;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xn + off);  // clamped address + select: no branch
+    tmp[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <typename G>
+__device__ __forceinline__ void brick_store(const G& g, int Cin, float* xs, const f32x4 (&tmp)[BRK_MAXP]) {
+#pragma unroll
+  for (int k = 0; k < BRK_MAXP; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < g.npieces) {
+      const int q = i % g.c4n, hv = i / g.c4n;
+      const int hw_ = hv % g.HWc, row = hv / g.HWc;
+      *reinterpret_cast<f32x4*>(xs + row * g.RS + hw_ * Cin + q * 4) = tmp[k];
+    }
+  }
+}
+
 // ---- the same brick, register-blocked over the row taps (2 output channels, KW = 5, <= 128 (kd, kh, quad)
 // triples: sr_head's 5x5x5 16->2).  A thread owns ALL KW taps of one (kd, kh, channel quad) for one of the two
 // brick slices: per brick row it reads the 12 x voxels and the 8 dY pairs once and forms 5 x 8 x 4 packed
@@ -889,6 +934,9 @@ __global__ __launch_bounds__(256) void small_cout2_wgrad_rows_kernel(const rehr_
     for (int e = 0; e < 4; ++e) acc[k][e] = f32x2_{0.f, 0.f};
   const int64_t nbricks = (int64_t)d.N * nb_d * nb_h * nb_w;
   const int64_t b0 = (int64_t)blockIdx.x * bricks_per_block;
+  const BrickGeom<HB_H + 4, HB_W + KW - 1, 4> geo = {RS, nrows * HW * c4n};  // KH = 5, Cin = 16 (dispatch)
+  f32x4 tmp[BRK_MAXP];
+  brick_fetch(d, geo, b0, nbricks, nb_d, nb_h, nb_w, tmp);
   for (int bi = 0; bi < bricks_per_block; ++bi) {
     const int64_t br = b0 + bi;
     if (br >= nbricks) break;
@@ -899,17 +947,8 @@ __global__ __launch_bounds__(256) void small_cout2_wgrad_rows_kernel(const rehr_
     const int n = (int)(r / nb_d);
     const int od0 = bd * HB_D, oh0 = bh * HB_H, ow0 = bw * HB_W;
     __syncthreads();  // previous brick fully consumed
-    const float* xn = d.x + (int64_t)n * d.Di * d.Hi * d.Wi * d.ldx;
-    for (int i = threadIdx.x; i < nrows * HW * c4n; i += 256) {
-      const int q = i % c4n, hv = i / c4n;
-      const int hw_ = hv % HW, row = hv / HW;
-      const int hh_ = row % HH, hd_ = row / HH;
-      const int id = od0 - d.pd + hd_, ih = oh0 - d.ph + hh_, iw = ow0 - d.pw + hw_;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi && (unsigned)iw < (unsigned)d.Wi)
-        v = *reinterpret_cast<const f32x4*>(xn + (((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx + q * 4);
-      *reinterpret_cast<f32x4*>(xs + row * RS + hw_ * d.Cin + q * 4) = v;
-    }
+    brick_store(geo, d.Cin, xs, tmp);
+    brick_fetch(d, geo, (bi + 1 < bricks_per_block) ? br + 1 : nbricks, nbricks, nb_d, nb_h, nb_w, tmp);
     for (int i = threadIdx.x; i < HB_VOX * 2; i += 256) {
       const int c = i & 1, v = i >> 1;
       const int vw = v % HB_W, vh = (v / HB_W) % HB_H, vd = v / (HB_W * HB_H);
@@ -1116,7 +1155,8 @@ extern "C" int rehr_conv_small_cout_wgrad_f32(const rehr_direct_conv_desc* dp, f
     const int64_t hv = (int64_t)(HB_D + d.KD - 1) * (HB_H + d.KH - 1) * (HB_W + d.KW - 1);
     const size_t hsmem = (size_t)(hv * d.Cin + HB_VOX * CO) * sizeof(float);
     const int64_t rows_floats = (int64_t)(HB_D + d.KD - 1) * (HB_H + d.KH - 1) * ((HB_W + 4) * d.Cin + 16) + HB_VOX * 2;
-    if (CO == 2 && d.KW == 5 && d.KD * d.KH * (d.Cin / 4) <= 128 && rows_floats * 4 <= 64 * 1024) {
+    if (CO == 2 && d.KW == 5 && d.KH == 5 && d.KD == 5 && d.Cin == 16 && rows_floats * 4 <= 64 * 1024 &&
+        (HB_D + d.KD - 1) * (HB_H + d.KH - 1) * (HB_W + 4) * (d.Cin / 4) <= BRK_MAXP * 256) {
       static const bool old_kernel = getenv("REHR_THIN_WGRAD_OLD") != nullptr;  // A/B switch for benchmarking
       if (!old_kernel) {
         hipLaunchKernelGGL(small_cout2_wgrad_rows_kernel<5>, dim3(hblocks), dim3(256), (size_t)rows_floats * 4, st, d,
