@@ -1,4 +1,4 @@
-"""FLAVR decoder transposed convs (3,4,4)/(1,2,2): forward + input gradient, 12-wave vs 4-wave F(2x2,2x2) kernel."""
+"""FLAVR decoder transposed convs (3,4,4)/(1,2,2): forward + input gradient timing (F(2x2,2x2) kernels)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,8 +19,7 @@ for (Cin, Cout, dims) in [(512, 128, (128, 16, 16)), (256, 64, (128, 32, 32)), (
     b = torch.zeros(Cout, device=dev)
     cfg = ops.ConvCfg((1, 2, 2), (1, 1, 1), True)
     res = {}
-    for mode in ("0", "1", "0", "1"):
-        os.environ["REHR_WINO22_4WAVE"] = mode
+    for mode in ("0",):
         y, _ = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.2, 0)
         dy = torch.ones_like(y) if "dy" not in res else res["dy"]
         res["dy"] = dy
@@ -33,4 +32,4 @@ for (Cin, Cout, dims) in [(512, 128, (128, 16, 16)), (256, 64, (128, 32, 32)), (
         else:
             e1 = ((y - res["y"]).abs().max() / res["y"].abs().max()).item()
             e2 = ((dx - res["dx"]).abs().max() / res["dx"].abs().max()).item()
-        print(f"{Cin}->{Cout} {dims} 4wave={mode}: fwd {tf:6.3f} ms  dgrad {tb:6.3f} ms  diff {e1:.1e} {e2:.1e}", flush=True)
+        print(f"{Cin}->{Cout} {dims}: fwd {tf:6.3f} ms  dgrad {tb:6.3f} ms  diff {e1:.1e} {e2:.1e}", flush=True)
