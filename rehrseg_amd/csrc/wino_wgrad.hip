@@ -295,12 +295,14 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[fa][fb][c][k] = 0.f;
-  // A k-group = NS steps of 4 MFMAs (one tile pair e of one quarter), each its own scheduling region.  With one
+  // A k-group = NS steps of 4 MFMAs (one tile pair e of one quarter); a quarter (4 steps) is one scheduling region
+  // and the accumulator anchors below keep every step's MFMAs in place inside it.  With one
   // wave per SIMD nothing hides a wait but the wave's own MFMAs in flight, so the work between them is laid out
-  // by hand: the LDS reads of an operand set are issued SPC steps before its transform, the LDS stores of the
+  // by hand: the LDS reads of an operand set are issued one step before its transform (measured: 1 step / quarter
+  // regions 4-5 % faster than 2 steps / per-step regions; whole-k-group regions slower again), the LDS stores of the
   // pieces fetched during the previous k-group go into the first half of the steps, their refill (address
   // arithmetic + global loads) into the second half, the cursor moves at the end.  Everything is branch-free.
-  constexpr int NS = 4 * C::NQ, SPC = (NS >= 16) ? 2 : 1, NPREP = C::NPREP;
+  constexpr int NS = 4 * C::NQ, SPC = 1, NPREP = C::NPREP;
   auto kgroup = [&](f32x4 (&ZS)[FA][4], f32x4 (&VS)[FB][4], int pbuf, const int pg, f32x4 (&ZN)[FA][4],
                     f32x4 (&VN)[FB][4], int sbuf, auto second_) {
     // first k-group of a stage: stores the second half of the pieces, refills the first half; second: vice versa
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
     Raw raw[2];
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
-      __builtin_amdgcn_sched_barrier(0);
+      if ((s_ & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // one scheduling region per quarter (16 MFMAs)
 #pragma unroll
       for (int j = 0; j < NPREP; ++j) {
         if (s_ == (j + 1) * SPC) prep_xform(j, raw[j & 1], ZN, VN);
