@@ -295,6 +295,18 @@ int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, int32_t Di,
                              int32_t Do, int64_t HW, int32_t C, int32_t KD, int32_t pd,
                              void* stream);
 
+/* Stem of the distillation teacher's overlapping 4-slice windows (get_intermediate_features,
+ * train_all.py:85-112 -> UNet_3D_3D.forward's mean subtraction FLAVR_arch.py:181 -> BasicStem
+ * resnet_3D.py:42-50).  g0..g2 = the (1,kH,kW) part of the stem's three depth taps on every slice of the
+ * depth-padded volume (B*nslices slices, NHWC) followed by one more "slice": the response to a
+ * constant 1 in channel 0.  y[b*nwin + w][k][hw][c] = act(bias[c] + sum over the taps kd that stay inside
+ * the window (0 <= k+kd-1 <= 3) of g[kd][b*nslices + w + k+kd-1] - mean[b*nwin + w] * g[kd][B*nslices]).
+ * nslices = nwin + 3.  No gradient (the teacher is frozen).                                           */
+int rehr_window_stem_assemble_f32(const float* g0, const float* g1, const float* g2,
+                                  const float* mean, const float* bias, float* y, int32_t B,
+                                  int32_t nwin, int32_t nslices, int64_t HW, int32_t C,
+                                  int32_t act, float slope, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Fused segmentation loss: softmax + cross-entropy, optionally
  * weighted by the uncertainty map with the reference's (B,D,H,W)*(B,1,D,H,W)

@@ -471,6 +471,48 @@ __global__ void upmix_depth_bwd_kernel(const float* __restrict__ dz, float* __re
   }
 }
 
+// ---------------------------------------------------------------- stem of overlapping depth windows
+// The distillation teacher runs UNet_3D_3D's encoder on every 4-slice window of a volume (train_all.py:85-112):
+// neighbouring windows share 3 of their 4 slices, and the stem conv (3 depth taps, zero padding at the WINDOW's
+// borders, per-window mean subtracted from channel 0 first, FLAVR_arch.py:181) is linear, so its (kH,kW) part is
+// taken once per volume slice and depth tap -- g[kd][slice][hw][c], the last "slice" being the response r[kd] to a
+// constant 1 in channel 0 -- and this kernel assembles window w, slice k:
+//   y[w][k][hw][c] = relu(bias[c] + sum_{kd: 0 <= k+kd-1 <= 3} (g[kd][w+k+kd-1][hw][c] - mean[w] * r[kd][hw][c]))
+// 4x fewer multiplications than convolving every window.  nslices = slices per sample incl. the padding (= nwin + 3).
+__global__ void window_stem_assemble_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
+                                            const float* __restrict__ g2, const float* __restrict__ mean,
+                                            const float* __restrict__ bias, float* __restrict__ y, int B, int nwin,
+                                            int nslices, int64_t HW, int C, int act, float slope) {
+  const int cq = C / 4;
+  const int64_t plane = HW * cq;
+  const int64_t total = (int64_t)B * nwin * 4 * plane;
+  const f32x4* gs[3] = {reinterpret_cast<const f32x4*>(g0), reinterpret_cast<const f32x4*>(g1),
+                        reinterpret_cast<const f32x4*>(g2)};
+  const int64_t rslice = (int64_t)B * nslices;  // index of the constant-1 response
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % plane;
+    int64_t r = i / plane;
+    const int k = (int)(r % 4); r /= 4;
+    const int w = (int)(r % nwin);
+    const int b = (int)(r / nwin);
+    const int q = (int)(p % cq);
+    const float m = mean[(int64_t)b * nwin + w];
+    f32x4 s = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int ks = k + kd - 1;  // window slice this tap reads
+      if (ks < 0 || ks > 3) continue;
+      const f32x4 gv = gs[kd][((int64_t)b * nslices + w + ks) * plane + p];
+      const f32x4 rv = gs[kd][rslice * plane + p];
+      s += gv - rv * m;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = apply_act(s[e], act, slope);
+    reinterpret_cast<f32x4*>(y)[i] = s;
+  }
+}
+
 // ---------------------------------------------------------------- misc
 __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
                                int act, float slope) {
@@ -740,6 +782,19 @@ extern "C" int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, i
   const int64_t total = (int64_t)N * Di * HW * KD * C / 4;
   hipLaunchKernelGGL(upmix_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dz, dg, N, Di, Do, HW,
                      C, KD, pd);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_window_stem_assemble_f32(const float* g0, const float* g1, const float* g2, const float* mean,
+                                             const float* bias, float* y, int32_t B, int32_t nwin, int32_t nslices,
+                                             int64_t HW, int32_t C, int32_t act, float slope, void* stream) {
+  if (!g0 || !g1 || !g2 || !mean || !y || B < 1 || nwin < 1 || nslices != nwin + 3 || HW < 1 || C < 4 || C % 4 ||
+      !aligned16(g0) || !aligned16(g1) || !aligned16(g2) || !aligned16(y) || (bias && !aligned16(bias)))
+    return REHR_EINVAL;
+  const int64_t total = (int64_t)B * nwin * 4 * HW * C / 4;
+  hipLaunchKernelGGL(window_stem_assemble_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g0, g1, g2, mean,
+                     bias, y, B, nwin, nslices, HW, C, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

@@ -424,6 +424,19 @@ def upmix_depth_bwd(dz, Di, KD, pd):
     return dg
 
 
+def window_stem_assemble(g, mean, bias, B, nwin, act, slope):
+    """g = three (B*(nwin+3)+1, C, 1, h, w) NDHWC per-tap responses -> y (B*nwin, C, 4, h, w) (see the header)."""
+    _chk_dev(*g, mean, bias)
+    S, Cc, _, h, w = g[0].shape
+    if S != B * (nwin + 3) + 1:
+        raise ValueError("window_stem_assemble: slice count")
+    y = new_act(B * nwin, Cc, 4, h, w, like=g[0])
+    L.check(L.load().rehr_window_stem_assemble_f32(_ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(mean), _ptr(bias), _ptr(y),
+                                                   B, nwin, nwin + 3, h * w, Cc, act, slope, _stream()),
+            "rehr_window_stem_assemble_f32")
+    return y
+
+
 def act_fwd(x, act, slope):
     _chk_dev(x)
     y = torch.empty_like(x)

@@ -83,6 +83,32 @@ class _Encoder(nn.Module):
         return tuple(feats)
 
 
+def encoder_on_windows(enc, xpad, nwin, upto):
+    """x_0..x_upto of the `nwin` overlapping 4-slice windows xpad[:, :, w:w+4] of a depth-padded volume
+    (B, C, nwin+3, H, W), each window with UNet_3D_3D.forward's mean subtraction on channel 0
+    (FLAVR_arch.py:181) -- what `encoder(windows)` returns for get_intermediate_features' window batch
+    (train_all.py:85-112), without convolving the shared slices once per window: the stem is linear, so the
+    (7,7) part of each of its 3 depth taps runs once per volume slice (plus once on a constant-1 image for the
+    mean term) and one HBM-bound pass assembles the windows.  No autograd (frozen teacher)."""
+    s = enc.stem[0]
+    B, C, Dp, H, W = xpad.shape
+    if Dp != nwin + 3 or tuple(s.weight.shape[2:]) != (3, 7, 7):
+        raise ValueError("encoder_on_windows: depth-padded volume of nwin + 3 slices, (3,7,7) stem")
+    with torch.no_grad():
+        sl = xpad.permute(0, 2, 1, 3, 4).reshape(B * Dp, C, 1, H, W)
+        one = torch.zeros((1, C, 1, H, W), dtype=xpad.dtype, device=xpad.device)
+        one[:, 0] = 1.0
+        inp = ops.to_cl(torch.cat([sl, one], dim=0))
+        g = [ops.fused_conv3d(inp, s.weight[:, :, kd:kd + 1].contiguous(), None, (1, 2, 2), (0, 3, 3)) for kd in range(3)]
+        ssum = xpad[:, 0].sum(dim=(2, 3))                                            # (B, Dp)
+        mean = (ssum[:, 0:nwin] + ssum[:, 1:nwin + 1] + ssum[:, 2:nwin + 2] + ssum[:, 3:nwin + 3]) / (4.0 * H * W)
+        x0 = ops.get_backend().window_stem_assemble(g, mean.contiguous(), s.bias, B, nwin, ops.ACT_RELU, 0.0)
+        feats = [x0]
+        for i in range(1, upto + 1):
+            feats.append(getattr(enc, f"layer{i}")(feats[-1]))
+    return tuple(feats)
+
+
 def unet_18(pretrained=False, bn=False, progress=True, img_channels=3, **kwargs):
     if pretrained:
         raise NotImplementedError("pretrained download is unavailable offline (the reference never enables it)")

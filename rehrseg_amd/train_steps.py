@@ -26,17 +26,23 @@ def get_intermediate_features(model_sr, img_lr, label_lr, device=None, levels=No
     if D < 2:
         raise ValueError("need at least two slices")
     padded = F.pad(x, (0, 0, 0, 0, 1, 2))                       # [0, x_0 .. x_{D-1}, 0, 0] along depth
-    # window st = padded[st : st+4], st = 0 .. D-2 (zero slice in front of the first, behind the last)
-    win = padded.unfold(2, 4, 1)[:, :, :D - 1]                  # (B, 2, D-1, H, W, 4)
-    win = win.permute(0, 2, 1, 5, 3, 4).reshape(B * (D - 1), C, 4, H, W).contiguous()
     upto = 4 if levels is None else max(levels)
     enc = getattr(model_sr, "encoder", None)
-    if upto < 4 and enc is not None and "upto" in enc.forward.__code__.co_varnames:
-        mean_ = win[:, 0:1].mean(2, keepdim=True).mean(3, keepdim=True).mean(4, keepdim=True)
-        win[:, 0:1] = win[:, 0:1] - mean_                       # UNet_3D_3D.forward's mean subtraction
-        feats = enc(win, upto=upto)
+    truncated = upto < 4 and enc is not None and "upto" in enc.forward.__code__.co_varnames
+    if truncated and not torch.is_grad_enabled() and H % 2 == 0 and W % 2 == 0:
+        # frozen teacher: the stem's per-slice work is shared between the overlapping windows
+        from .models.FLAVR.resnet_3D import encoder_on_windows
+        feats = encoder_on_windows(enc, padded[:, :, :D + 2], D - 1, upto)  # (the windows never reach the last slice)
     else:
-        feats = model_sr(win, return_inetermediate_feature=True)
+        # window st = padded[st : st+4], st = 0 .. D-2 (zero slice in front of the first, behind the last)
+        win = padded.unfold(2, 4, 1)[:, :, :D - 1]              # (B, 2, D-1, H, W, 4)
+        win = win.permute(0, 2, 1, 5, 3, 4).reshape(B * (D - 1), C, 4, H, W).contiguous()
+        if truncated:
+            mean_ = win[:, 0:1].mean(2, keepdim=True).mean(3, keepdim=True).mean(4, keepdim=True)
+            win[:, 0:1] = win[:, 0:1] - mean_                   # UNet_3D_3D.forward's mean subtraction
+            feats = enc(win, upto=upto)
+        else:
+            feats = model_sr(win, return_inetermediate_feature=True)
     out = {}
     for i, f in enumerate(feats):
         if levels is not None and i not in levels:

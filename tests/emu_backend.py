@@ -282,6 +282,23 @@ def upmix_depth_bwd(dz, Di, KD, pd):
     return dg.contiguous(memory_format=torch.channels_last_3d)
 
 
+def window_stem_assemble(g, mean, bias, B, nwin, act, slope):
+    S, Cc, _, h, w = g[0].shape
+    ns = nwin + 3
+    gs = [t[:-1, :, 0].reshape(B, ns, Cc, h, w) for t in g]
+    rs = [t[-1, :, 0] for t in g]
+    out = torch.zeros(B, nwin, Cc, 4, h, w, dtype=g[0].dtype)
+    m = mean.reshape(B, nwin, 1, 1, 1)
+    for k in range(4):
+        for kd in range(3):
+            ks = k + kd - 1
+            if 0 <= ks <= 3:
+                out[:, :, :, k] += gs[kd][:, ks:ks + nwin] - m * rs[kd]
+    if bias is not None:
+        out = out + bias.view(1, 1, -1, 1, 1, 1)
+    return _act(out.reshape(B * nwin, Cc, 4, h, w), act, slope).contiguous(memory_format=torch.channels_last_3d)
+
+
 def act_fwd(x, act, slope):
     return _act(x, act, slope)
 
