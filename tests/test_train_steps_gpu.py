@@ -83,3 +83,26 @@ def test_train_segsr_step_with_distillation():
     ref = ref + ao.robust_ce(seg_sr, lab_hr[:, 0], None) - dc.mean()
     ref = ref + ao.distiller_loss(dsd["distill.weight"], dsd["distill.bias"], skips[1], tf[1], 0.0, 1.0, 1.0)
     assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+
+
+def test_teacher_stem_shared_between_windows_gpu():
+    """encoder_on_windows (per-slice stem responses + window assembly) against the encoder run on the explicit window
+    batch with UNet_3D_3D.forward's per-window mean subtraction (ref train_all.py:85-112, FLAVR_arch.py:181)."""
+    import torch.nn.functional as F
+    from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+    from rehrseg_amd.models.FLAVR.resnet_3D import encoder_on_windows
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    enc = UNet_3D_3D(2, "unet_18", 4, 4, use_uncertainty=True).to(dev).eval().encoder
+    B, D, H, W = 2, 9, 64, 48
+    x = torch.randn(B, 2, D, H, W, device=dev) * 2 + 0.7
+    padded = F.pad(x, (0, 0, 0, 0, 1, 2))
+    with torch.no_grad():
+        got = encoder_on_windows(enc, padded[:, :, :D + 2], D - 1, 1)
+        win = padded.unfold(2, 4, 1)[:, :, :D - 1].permute(0, 2, 1, 5, 3, 4).reshape(B * (D - 1), 2, 4, H, W).contiguous()
+        win[:, 0:1] = win[:, 0:1] - win[:, 0:1].mean(dim=(2, 3, 4), keepdim=True)
+        ref = enc(win, upto=1)
+    for a, e in zip(got, ref):
+        assert a.shape == e.shape
+        err = ((a - e).abs().max() / e.abs().max()).item()
+        assert err <= 2e-5, err
