@@ -295,6 +295,16 @@ int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, int32_t Di,
                              int32_t Do, int64_t HW, int32_t C, int32_t KD, int32_t pd,
                              void* stream);
 
+/* Max-pool of every (sample, depth) slice with a (H/2, W/2) window and stride: the 2x2 summary per slice and
+ * channel that Distiller's structure loss compares (CriterionPairWiseforWholeFeatAfterPool,
+ * models/seg_model.py:95-113; MaxPool2d(ceil_mode=True) with even H, W).  x [slices][H][W][C] (NDHWC slices),
+ * y [slices][2][2][C], idx = row-major position of the first maximum inside its slice (for the backward).
+ * bwd: dx is zero-filled, then dx[slice][idx][c] = dy[slice][q][c].                                          */
+int rehr_quad_maxpool_fwd_f32(const float* x, float* y, int32_t* idx, int64_t slices,
+                              int32_t H, int32_t W, int32_t C, void* stream);
+int rehr_quad_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int64_t slices,
+                              int32_t H, int32_t W, int32_t C, void* stream);
+
 /* Stem of the distillation teacher's overlapping 4-slice windows (get_intermediate_features,
  * train_all.py:85-112 -> UNet_3D_3D.forward's mean subtraction FLAVR_arch.py:181 -> BasicStem
  * resnet_3D.py:42-50).  g0..g2 = the (1,kH,kW) part of the stem's three depth taps on every slice of the

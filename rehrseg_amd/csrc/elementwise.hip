@@ -513,6 +513,58 @@ __global__ void window_stem_assemble_kernel(const float* __restrict__ g0, const 
   }
 }
 
+// ---------------------------------------------------------------- quadrant max-pool (Distiller's structure loss)
+// CriterionPairWiseforWholeFeatAfterPool (models/seg_model.py:95-113) max-pools every (sample, depth) slice of a
+// 64-channel feature map with a (H/2, W/2) window: 4 outputs per slice and channel.  ATen's NHWC pooling kernel
+// walks such a window serially per output (0.55 ms for 128 slices of 64x64); here a block owns one (slice,
+// quadrant): lanes = channels (coalesced voxel records), 4 row groups, one LDS step.  idx = row-major position
+// of the FIRST maximum inside the slice (what MaxPool2d's backward uses).
+__global__ __launch_bounds__(256) void quad_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               int* __restrict__ idx, int H, int W, int C) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int slice = blockIdx.x >> 2, qd = blockIdx.x & 3;
+  const int ph = H / 2, pw = W / 2;
+  const int h0 = (qd >> 1) * ph, w0 = (qd & 1) * pw;
+  const int lanes = C < 256 ? C : 256, groups = 256 / lanes;
+  const int c_l = threadIdx.x % lanes, g = threadIdx.x / lanes;
+  for (int c = c_l; c < C; c += lanes) {
+    float best = -INFINITY;
+    int bi = (h0 * W + w0);
+    if (g < groups) {
+      for (int r = g; r < ph; r += groups) {
+        const float* row = x + (((int64_t)slice * H + h0 + r) * W + w0) * C + c;
+        for (int q = 0; q < pw; ++q) {
+          const float v = row[(int64_t)q * C];
+          if (v > best || v != v) { best = v; bi = (h0 + r) * W + w0 + q; }  // (NaN propagates like ATen)
+        }
+      }
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    if (g == 0) {
+      for (int k = 1; k < groups; ++k) {
+        const float v = sv[k * lanes + c_l];
+        const int vi = si[k * lanes + c_l];
+        if (v > best || (v == best && vi < bi)) { best = v; bi = vi; }
+      }
+      y[((int64_t)slice * 4 + qd) * C + c] = best;
+      idx[((int64_t)slice * 4 + qd) * C + c] = bi;
+    }
+    __syncthreads();
+  }
+}
+// dx (zero-filled by the caller) [slice][idx][c] = dy[slice][quadrant][c]
+__global__ void quad_maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                        float* __restrict__ dx, int64_t total, int HW, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t slice = i / ((int64_t)4 * C);
+    dx[(slice * HW + idx[i]) * C + c] = dy[i];
+  }
+}
+
 // ---------------------------------------------------------------- misc
 __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
                                int act, float slope) {
@@ -795,6 +847,24 @@ extern "C" int rehr_window_stem_assemble_f32(const float* g0, const float* g1, c
   const int64_t total = (int64_t)B * nwin * 4 * HW * C / 4;
   hipLaunchKernelGGL(window_stem_assemble_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g0, g1, g2, mean,
                      bias, y, B, nwin, nslices, HW, C, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_quad_maxpool_fwd_f32(const float* x, float* y, int32_t* idx, int64_t slices, int32_t H, int32_t W,
+                                         int32_t C, void* stream) {
+  if (!x || !y || !idx || slices < 1 || slices * 4 >= (1ll << 31) || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1)
+    return REHR_EINVAL;
+  hipLaunchKernelGGL(quad_maxpool_fwd_kernel, dim3((unsigned)(slices * 4)), dim3(256), 0, ST, x, y, idx, H, W, C);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+extern "C" int rehr_quad_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int64_t slices, int32_t H,
+                                         int32_t W, int32_t C, void* stream) {
+  if (!dy || !idx || !dx || slices < 1 || H < 2 || W < 2 || C < 1) return REHR_EINVAL;
+  if (hipMemsetAsync(dx, 0, (size_t)slices * H * W * C * sizeof(float), ST) != hipSuccess) return REHR_EHIP;
+  const int64_t total = slices * 4 * C;
+  hipLaunchKernelGGL(quad_maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dy, idx, dx, total, H * W, C);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

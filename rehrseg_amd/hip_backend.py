@@ -437,6 +437,27 @@ def window_stem_assemble(g, mean, bias, B, nwin, act, slope):
     return y
 
 
+def quad_maxpool_fwd(x):
+    """x (N, C, D, H, W) NDHWC, H and W even -> (y (N*D, C, 2, 2) fp32 NHWC-dense, idx int32 same layout)."""
+    _chk_dev(x)
+    N, Cc, D, H, W = x.shape
+    y = torch.empty((N * D, Cc, 2, 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    idx = torch.empty((N * D, 2, 2, Cc), dtype=torch.int32, device=x.device)
+    L.check(L.load().rehr_quad_maxpool_fwd_f32(_ptr(x), _ptr(y), C.c_void_p(idx.data_ptr()), N * D, H, W, Cc, _stream()),
+            "rehr_quad_maxpool_fwd_f32")
+    return y, idx
+
+
+def quad_maxpool_bwd(dy, idx, shape):
+    _chk_dev(dy)
+    N, Cc, D, H, W = shape
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    dx = new_act(N, Cc, D, H, W, like=dy)
+    L.check(L.load().rehr_quad_maxpool_bwd_f32(_ptr(dy), C.c_void_p(idx.data_ptr()), _ptr(dx), N * D, H, W, Cc, _stream()),
+            "rehr_quad_maxpool_bwd_f32")
+    return dx
+
+
 def act_fwd(x, act, slope):
     _chk_dev(x)
     y = torch.empty_like(x)

@@ -255,6 +255,24 @@ def sim_dis_compute(f_S, f_T):
     return sim_err.sum()
 
 
+class _QuadMaxPool(torch.autograd.Function):
+    """MaxPool2d((H/2, W/2), stride = kernel) of every (sample, depth) slice on the device (rehr_quad_maxpool_*):
+    (B, C, S, H, W) -> (B*S, C, 2, 2); the gradient goes to the first maximum of each window, like ATen's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.to_cl(x)
+        y, idx = ops.get_backend().quad_maxpool_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.get_backend().quad_maxpool_bwd(dy, idx, ctx.shape)
+
+
 class CriterionPairWiseforWholeFeatAfterPool(nn.Module):
     def __init__(self, scale):
         super().__init__()
@@ -263,9 +281,13 @@ class CriterionPairWiseforWholeFeatAfterPool(nn.Module):
 
     def forward(self, preds_S, preds_T):
         _, _, s, total_w, total_h = preds_S.shape
+        patch_w, patch_h = int(total_w * self.scale), int(total_h * self.scale)
+        if (preds_S.is_cuda and preds_T.is_cuda and self.scale == 0.5 and total_w % 2 == 0 and total_h % 2 == 0 and
+                preds_S.dtype == torch.float32 and preds_T.dtype == torch.float32):
+            # even planes: the four windows tile the slice exactly (ceil_mode has nothing to add)
+            return self.criterion(_QuadMaxPool.apply(preds_S), _QuadMaxPool.apply(preds_T)) / s
         feat_S = rearrange(preds_S, "b c s h w -> (b s) c h w")
         feat_T = rearrange(preds_T, "b c s h w -> (b s) c h w")
-        patch_w, patch_h = int(total_w * self.scale), int(total_h * self.scale)
         maxpool = nn.MaxPool2d(kernel_size=(patch_w, patch_h), stride=(patch_w, patch_h), padding=0, ceil_mode=True)
         return self.criterion(maxpool(feat_S), maxpool(feat_T)) / s
 

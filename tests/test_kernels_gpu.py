@@ -385,3 +385,21 @@ def test_rejects_cpu_tensors():
     from rehrseg_amd.lib import RehrsegHipError
     with pytest.raises(RehrsegHipError):
         ops.fused_conv3d(torch.randn(1, 32, 2, 4, 4), torch.randn(32, 32, 3, 3, 3), None, 1, 1)
+
+
+def test_quad_maxpool_structure_loss():
+    """Distiller's per-slice (H/2, W/2) max-pool (ref models/seg_model.py:95-113) on the device against nn.MaxPool2d,
+    values and gradient (first maximum of a window)."""
+    from rehrseg_amd.models.seg_model import _QuadMaxPool
+    dev = _dev()
+    x = _mk(2, 64, 3, 12, 10, seed=90)
+    xg = x.to(dev).requires_grad_(True)
+    y = _QuadMaxPool.apply(xg)
+    xr = x.double().requires_grad_(True)
+    fr = xr.permute(0, 2, 1, 3, 4).reshape(6, 64, 12, 10)
+    ref = torch.nn.MaxPool2d(kernel_size=(6, 5), stride=(6, 5), padding=0, ceil_mode=True)(fr)
+    _close(y, ref, 0.0)
+    g = _mk(*ref.shape, seed=91)
+    (gx,) = torch.autograd.grad(y, xg, g.to(dev))
+    (rx,) = torch.autograd.grad(ref, xr, g.double())
+    _close(gx, rx, 0.0)
