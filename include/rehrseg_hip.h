@@ -295,6 +295,15 @@ int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, int32_t Di,
                              int32_t Do, int64_t HW, int32_t C, int32_t KD, int32_t pd,
                              void* stream);
 
+/* cosine_distance_loss (models/seg_model.py:60-78) on two (N, 64, D, H, W) NDHWC tensors, S = D*H*W:
+ * stats[n][c] = (S12, S11, S22) of the per-voxel channel-normalised tensors (fp64, zeroed by the call);
+ * loss = mean_{n,c}(1 - S12 / (max(sqrt(S11), 1e-8) * max(sqrt(S22), 1e-8))) is three lines of host code.
+ * bwd: gradient w.r.t. x1 only (x2 = the frozen teacher), scale = -dloss / (N*C).                   */
+int rehr_cosdist_stats_f32(const float* x1, const float* x2, double* stats, int32_t N,
+                           int64_t S, int32_t C, void* stream);
+int rehr_cosdist_bwd_f32(const float* x1, const float* x2, const double* stats, float* dx1,
+                         int32_t N, int64_t S, int32_t C, float scale, void* stream);
+
 /* Max-pool of every (sample, depth) slice with a (H/2, W/2) window and stride: the 2x2 summary per slice and
  * channel that Distiller's structure loss compares (CriterionPairWiseforWholeFeatAfterPool,
  * models/seg_model.py:95-113; MaxPool2d(ceil_mode=True) with even H, W).  x [slices][H][W][C] (NDHWC slices),

@@ -565,6 +565,59 @@ __global__ void quad_maxpool_bwd_kernel(const float* __restrict__ dy, const int*
   }
 }
 
+// ---------------------------------------------------------------- channel-normalised cosine distance (Distiller)
+// cosine_distance_loss (models/seg_model.py:60-78): t = x / max(|x[:, v]|_2, 1e-12) per voxel (F.normalize over
+// channels), then per (sample, channel) the cosine similarity of t1[c, :] and t2[c, :] over the flattened voxels,
+// loss = mean(1 - cos).  ATen runs it as ~10 passes over the two 64-channel tensors; here lane = channel (C == 64),
+// a wave = one voxel at a time: pass 1 accumulates S12, S11, S22 per (sample, channel) (fp64 atomics per block),
+// pass 2 (gradient w.r.t. x1 only: x2 is the frozen teacher) recomputes the voxel norms and applies
+//   g = -(gl / (N C)) (t2 / (a b) - S12 t1 / (a^3 b)),  a = max(sqrt(S11), eps), b = max(sqrt(S22), eps)
+//   dx1 = (g - t1 * sum_c(g t1)) / n1.
+__global__ __launch_bounds__(256) void cosdist_stats_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                            double* __restrict__ stats, int64_t S,
+                                                            int64_t vox_per_block) {
+  __shared__ float red[4][3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int64_t v0 = (int64_t)blockIdx.x * vox_per_block;
+  const int64_t v1 = min(S, v0 + vox_per_block);
+  float s12 = 0.f, s11 = 0.f, s22 = 0.f;
+  for (int64_t v = v0 + wave; v < v1; v += 4) {
+    const float a = x1[((int64_t)n * S + v) * 64 + lane], b = x2[((int64_t)n * S + v) * 64 + lane];
+    const float na = fmaxf(sqrtf(wave_sum(a * a)), 1e-12f), nb = fmaxf(sqrtf(wave_sum(b * b)), 1e-12f);
+    const float ta = a / na, tb = b / nb;
+    s12 += ta * tb;
+    s11 += ta * ta;
+    s22 += tb * tb;
+  }
+  red[wave][0][lane] = s12;
+  red[wave][1][lane] = s11;
+  red[wave][2][lane] = s22;
+  __syncthreads();
+  if (threadIdx.x < 192) {
+    const int k = threadIdx.x >> 6;
+    const float t = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+    atomicAdd(stats + ((int64_t)n * 64 + lane) * 3 + k, (double)t);
+  }
+}
+__global__ __launch_bounds__(256) void cosdist_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                          const double* __restrict__ stats, float* __restrict__ dx1,
+                                                          int64_t S, int64_t total_vox, float scale) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t gv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gv < total_vox; gv += (int64_t)gridDim.x * 4) {
+    const int n = (int)(gv / S);
+    const double* st = stats + ((int64_t)n * 64 + lane) * 3;
+    const float S12 = (float)st[0];
+    const float ca = fmaxf(sqrtf((float)st[1]), 1e-8f), cb = fmaxf(sqrtf((float)st[2]), 1e-8f);
+    const float a = x1[gv * 64 + lane], b = x2[gv * 64 + lane];
+    const float na = fmaxf(sqrtf(wave_sum(a * a)), 1e-12f), nb = fmaxf(sqrtf(wave_sum(b * b)), 1e-12f);
+    const float ta = a / na, tb = b / nb;
+    const float g = scale * (tb / (ca * cb) - S12 * ta / (ca * ca * ca * cb));
+    const float dot = wave_sum(g * ta);
+    dx1[gv * 64 + lane] = (g - ta * dot) / na;
+  }
+}
+
 // ---------------------------------------------------------------- misc
 __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
                                int act, float slope) {
@@ -865,6 +918,29 @@ extern "C" int rehr_quad_maxpool_bwd_f32(const float* dy, const int32_t* idx, fl
   if (hipMemsetAsync(dx, 0, (size_t)slices * H * W * C * sizeof(float), ST) != hipSuccess) return REHR_EHIP;
   const int64_t total = slices * 4 * C;
   hipLaunchKernelGGL(quad_maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dy, idx, dx, total, H * W, C);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_cosdist_stats_f32(const float* x1, const float* x2, double* stats, int32_t N, int64_t S, int32_t C,
+                                      void* stream) {
+  if (!x1 || !x2 || !stats || N < 1 || N > 65535 || S < 1 || C != 64) return REHR_EINVAL;
+  if (hipMemsetAsync(stats, 0, sizeof(double) * N * 64 * 3, ST) != hipSuccess) return REHR_EHIP;
+  int64_t blocks = 1024 / N > 0 ? 1024 / N : 1;
+  int64_t vpb = (S + blocks - 1) / blocks;
+  if (vpb < 64) vpb = 64;
+  blocks = (S + vpb - 1) / vpb;
+  hipLaunchKernelGGL(cosdist_stats_kernel, dim3((unsigned)blocks, N), dim3(256), 0, ST, x1, x2, stats, S, vpb);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+extern "C" int rehr_cosdist_bwd_f32(const float* x1, const float* x2, const double* stats, float* dx1, int32_t N,
+                                    int64_t S, int32_t C, float scale, void* stream) {
+  if (!x1 || !x2 || !stats || !dx1 || N < 1 || S < 1 || C != 64) return REHR_EINVAL;
+  const int64_t total = (int64_t)N * S;
+  int64_t blocks = (total + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(cosdist_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ST, x1, x2, stats, dx1, S, total, scale);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

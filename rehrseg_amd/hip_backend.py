@@ -437,6 +437,25 @@ def window_stem_assemble(g, mean, bias, B, nwin, act, slope):
     return y
 
 
+def cosdist_stats(x1, x2):
+    """(N, 64, D, H, W) NDHWC pair -> stats (N, 64, 3) fp64 = (S12, S11, S22) of the channel-normalised tensors."""
+    _chk_dev(x1, x2)
+    N, Cc, D, H, W = x1.shape
+    stats = torch.empty((N, Cc, 3), dtype=torch.float64, device=x1.device)
+    L.check(L.load().rehr_cosdist_stats_f32(_ptr(x1), _ptr(x2), _ptr(stats), N, D * H * W, Cc, _stream()),
+            "rehr_cosdist_stats_f32")
+    return stats
+
+
+def cosdist_bwd(x1, x2, stats, scale):
+    _chk_dev(x1, x2, stats)
+    N, Cc, D, H, W = x1.shape
+    dx = new_act(N, Cc, D, H, W, like=x1)
+    L.check(L.load().rehr_cosdist_bwd_f32(_ptr(x1), _ptr(x2), _ptr(stats), _ptr(dx), N, D * H * W, Cc, float(scale),
+                                          _stream()), "rehr_cosdist_bwd_f32")
+    return dx
+
+
 def quad_maxpool_fwd(x):
     """x (N, C, D, H, W) NDHWC, H and W even -> (y (N*D, C, 2, 2) fp32 NHWC-dense, idx int32 same layout)."""
     _chk_dev(x)

@@ -231,7 +231,29 @@ class SegModel(PlainConvUNet):
 # ----------------------------------------------------------------------------- distillation (seg_model.py:60-151)
 # HBM-bound reductions over two 64-channel tensors; torch ops on the device for now
 # (SURVEY section 8f-1 ranks their fusion as the next row).
+class _CosDist(torch.autograd.Function):
+    """cosine_distance_loss on the device in two passes (rehr_cosdist_*): gradient w.r.t. the first tensor only."""
+
+    @staticmethod
+    def forward(ctx, x1, x2):
+        x1, x2 = ops.to_cl(x1), ops.to_cl(x2)
+        stats = ops.get_backend().cosdist_stats(x1, x2)
+        ctx.save_for_backward(x1, x2, stats)
+        cos = stats[..., 0] / (stats[..., 1].sqrt().clamp_min(1e-8) * stats[..., 2].sqrt().clamp_min(1e-8))
+        return (1 - cos).mean().float()
+
+    @staticmethod
+    def backward(ctx, gl):
+        x1, x2, stats = ctx.saved_tensors
+        scale = -float(gl) / (stats.shape[0] * stats.shape[1])
+        return ops.get_backend().cosdist_bwd(x1, x2, stats, scale), None
+
+
 def cosine_distance_loss(tensor1, tensor2):
+    if (tensor1.is_cuda and tensor2.is_cuda and tensor1.dim() == 5 and tensor1.shape[1] == 64 and
+            tensor1.shape == tensor2.shape and tensor1.dtype == torch.float32 and tensor2.dtype == torch.float32 and
+            not tensor2.requires_grad):
+        return _CosDist.apply(tensor1, tensor2)
     t1 = F.normalize(tensor1, p=2, dim=1)
     t2 = F.normalize(tensor2, p=2, dim=1)
     t1 = t1.reshape(t1.shape[0], t1.shape[1], -1)

@@ -403,3 +403,21 @@ def test_quad_maxpool_structure_loss():
     (gx,) = torch.autograd.grad(y, xg, g.to(dev))
     (rx,) = torch.autograd.grad(ref, xr, g.double())
     _close(gx, rx, 0.0)
+
+
+def test_cosine_distance_loss_fused():
+    """Distiller's cosine_distance_loss (ref models/seg_model.py:60-78) in two device passes against the torch
+    composition in fp64: value and gradient w.r.t. the student tensor."""
+    from rehrseg_amd.models import seg_model as sm
+    dev = _dev()
+    a, b = _mk(2, 64, 3, 10, 12, seed=92), _mk(2, 64, 3, 10, 12, seed=93) * 0.5 + 0.1
+    ag = a.to(dev).requires_grad_(True)
+    loss = sm.cosine_distance_loss(ag, b.to(dev))
+    ar = a.double().requires_grad_(True)
+    t1 = F.normalize(ar, p=2, dim=1).reshape(2, 64, -1)
+    t2 = F.normalize(b.double(), p=2, dim=1).reshape(2, 64, -1)
+    ref = (1 - torch.cosine_similarity(t1, t2, dim=2)).mean()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item()))
+    (g,) = torch.autograd.grad(loss, ag)
+    (gr,) = torch.autograd.grad(ref, ar)
+    _close(g, gr, 1e-4)
