@@ -50,6 +50,14 @@ class PatchParallel:
         for p in self.params:
             if p.dim() == 5 and p.is_cuda:
                 ops._direct_grad[p.data_ptr()] = (p, self)
+        # every other parameter (biases, norm / gate parameters: dozens of tiny tensors) gets `.grad = None` at
+        # zero_grad, so autograd hands its gradient over without an add kernel each (0.7-1.0 ms of 10 us launches
+        # per step); the values are copied into the flat buffer bucket-wise, right before a bucket's exchange
+        self._steal = [p for p in self.params if not (p.dim() == 5 and p.is_cuda)]
+        self._view = {id(p): p.grad for p in self._steal}
+        self._steal_of_bucket = [[] for _ in self.buckets]
+        for p in self._steal:
+            self._steal_of_bucket[self._bucket_of[p]].append(p)
         self.overlap = overlap and self.world > 1
         self._pending = [b[2] for b in self.buckets]
         self._works = []
@@ -64,8 +72,17 @@ class PatchParallel:
                 dist.broadcast(b.data, src=0, group=process_group)
 
     # ------------------------------------------------------------------ bucket exchange
+    def _collect(self, i):
+        """Bucket i's handed-over gradients -> their slots of the flat buffer; `.grad` becomes the view again."""
+        ps = [p for p in self._steal_of_bucket[i] if p.grad is not None and p.grad is not self._view[id(p)]]
+        if ps:
+            torch._foreach_copy_([self._view[id(p)] for p in ps], [p.grad for p in ps])
+            for p in ps:
+                p.grad = self._view[id(p)]
+
     def _launch(self, i):
         s, e, _ = self.buckets[i]
+        self._collect(i)
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._launched[i] = True
 
@@ -88,6 +105,8 @@ class PatchParallel:
     def zero_grad(self):
         """Keeps the .grad views (optimizer.zero_grad(set_to_none=True) would drop them)."""
         self.flat.zero_()
+        for p in self._steal:
+            p.grad = None
         self._written.clear()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
@@ -98,7 +117,7 @@ class PatchParallel:
         Buckets whose hooks did not fire (parameters without a gradient this step, or
         overlap disabled) are exchanged here."""
         if self.world == 1:
-            return
+            return  # (handed-over gradients stay where autograd put them: the optimizer reads p.grad)
         for i in range(len(self.buckets)):
             if not self._launched[i]:
                 self._launch(i)
@@ -106,6 +125,9 @@ class PatchParallel:
             w.wait()
         self._works = []
         self.flat.div_(self.world)
+        for p in self._steal:  # parameters without a gradient this step: back to the (zero) view, like before
+            if p.grad is None:
+                p.grad = self._view[id(p)]
 
     def grad_bytes(self):
         return self.flat.numel() * self.flat.element_size()
