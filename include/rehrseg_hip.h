@@ -287,13 +287,17 @@ int rehr_upsample_depth_bwd_f32(const float* dy, float* dx, int32_t N,
  * convolution with KD*C output channels on the ordinary conv path -- and
  *   y[n][d][hw][co] = act(bias[co] + sum_kd [0 <= u < Do] ((1-t) g[n][i0][hw][kd*C+co] + t g[n][i1][..])),
  *   u = d + kd - pd, (i0, i1, t) = align_corners source of upsampled slice u.
- * bwd: dg from dz = dy * act'(y) (rehr_act_bwd_f32).  C % 4 == 0.                                */
+ * bwd: dg from dz = dy * act'(y), formed on the fly from dy and the saved output y.  C % 4 == 0.    */
 int rehr_upmix_depth_fwd_f32(const float* g, const float* bias, float* y, int32_t N,
                              int32_t Di, int32_t Do, int64_t HW, int32_t C, int32_t KD,
                              int32_t pd, int32_t act, float slope, void* stream);
-int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, int32_t Di,
-                             int32_t Do, int64_t HW, int32_t C, int32_t KD, int32_t pd,
-                             void* stream);
+int rehr_upmix_depth_bwd_f32(const float* dy, const float* y, float* dg, int32_t N,
+                             int32_t Di, int32_t Do, int64_t HW, int32_t C, int32_t KD,
+                             int32_t pd, int32_t act, float slope, void* stream);
+/* out[c] = sum over rows of dy[row][c] * act'(y[row][c]): the bias gradient behind a fused activation */
+int rehr_channel_sum_actgrad_f32(const float* dy, const float* y, int32_t ld, int64_t rows,
+                                 int32_t C, int32_t act, float slope, float* out,
+                                 double* scratch, void* stream);
 
 /* cosine_distance_loss (models/seg_model.py:60-78) on two (N, 64, D, H, W) NDHWC tensors, S = D*H*W:
  * stats[n][c] = (S12, S11, S22) of the per-voxel channel-normalised tensors (fp64, zeroed by the call);

@@ -437,8 +437,9 @@ __global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float*
   }
 }
 // dG[n][j][hw][kd*C+co] = sum over upsampled slices ud with source j of coef(ud, j) * dz[n][ud - kd + p][hw][co]
-__global__ void upmix_depth_bwd_kernel(const float* __restrict__ dz, float* __restrict__ dg, int N, int Di, int Do,
-                                       int64_t HW, int C, int KD, int pd) {
+__global__ void upmix_depth_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ yact,
+                                       float* __restrict__ dg, int N, int Di, int Do, int64_t HW, int C, int KD,
+                                       int pd, int act, float slope) {
   const int cq = C / 4;
   const int64_t gplane = HW * KD * cq;
   const int64_t plane = HW * cq;
@@ -465,7 +466,16 @@ __global__ void upmix_depth_bwd_kernel(const float* __restrict__ dz, float* __re
       float wgt = 0.f;
       if (i0 == id) wgt += 1.f - w1;
       if (i1 == id) wgt += w1;
-      if (wgt != 0.f) s += reinterpret_cast<const f32x4*>(dz)[((int64_t)n * Do + od) * plane + hw * cq + q] * wgt;
+      if (wgt != 0.f) {
+        const int64_t o = ((int64_t)n * Do + od) * plane + hw * cq + q;
+        f32x4 d = reinterpret_cast<const f32x4*>(dz)[o];
+        if (yact != nullptr) {  // dz = dy * act'(y) on the fly: no separate activation-gradient pass
+          const f32x4 yv = reinterpret_cast<const f32x4*>(yact)[o];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] *= act_grad(yv[e], act, slope);
+        }
+        s += d * wgt;
+      }
     }
     reinterpret_cast<f32x4*>(dg)[i] = s;
   }
@@ -651,6 +661,20 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int ldx, int64_t
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] += v[e];
+  });
+}
+// column sums of dy * act'(y): the bias gradient behind a fused activation without materialising dz
+__global__ void channel_sum_actgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
+                                           int64_t rows, int C, int64_t rows_per_block, int act, float slope,
+                                           double* __restrict__ scratch) {
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  column_reduce<1>(r_begin, r_end, C, scratch, 1, [&](int64_t row, int c, double(&acc)[1][4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(dy + row * ld + c);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ld + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][e] += v[e] * act_grad(yv[e], act, slope);
   });
 }
 __global__ void channel_sum_finish_kernel(const double* __restrict__ scratch, float* __restrict__ out,
@@ -879,14 +903,15 @@ extern "C" int rehr_upmix_depth_fwd_f32(const float* g, const float* bias, float
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
-extern "C" int rehr_upmix_depth_bwd_f32(const float* dz, float* dg, int32_t N, int32_t Di, int32_t Do, int64_t HW,
-                                        int32_t C, int32_t KD, int32_t pd, void* stream) {
+extern "C" int rehr_upmix_depth_bwd_f32(const float* dz, const float* y, float* dg, int32_t N, int32_t Di, int32_t Do,
+                                        int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
+                                        void* stream) {
   if (!dz || !dg || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || KD < 1 || pd < 0 || pd >= KD ||
-      !aligned16(dz) || !aligned16(dg))
+      !aligned16(dz) || !aligned16(dg) || (y && !aligned16(y)))
     return REHR_EINVAL;
   const int64_t total = (int64_t)N * Di * HW * KD * C / 4;
-  hipLaunchKernelGGL(upmix_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dz, dg, N, Di, Do, HW,
-                     C, KD, pd);
+  hipLaunchKernelGGL(upmix_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dz,
+                     act == REHR_ACT_NONE ? nullptr : y, dg, N, Di, Do, HW, C, KD, pd, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -974,6 +999,21 @@ extern "C" int rehr_channel_sum_f32(const float* x, int32_t ldx, int64_t rows, i
                      scratch);
   hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, scratch, out, C,
                      accumulate);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_channel_sum_actgrad_f32(const float* dy, const float* y, int32_t ld, int64_t rows, int32_t C,
+                                            int32_t act, float slope, float* out, double* scratch, void* stream) {
+  if (!dy || !y || !out || !scratch || rows < 1 || C < 4 || C % 4 || C > 1024 || ld % 4 || !aligned16(dy) ||
+      !aligned16(y))
+    return REHR_EINVAL;
+  if (hipMemsetAsync(scratch, 0, sizeof(double) * C, ST) != hipSuccess) return REHR_EHIP;
+  const int64_t rpb = rows_per_block_for(rows, C, 1);
+  const int blocks = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(channel_sum_actgrad_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST, dy, y, ld, rows, C, rpb, act,
+                     slope, scratch);
+  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, scratch, out, C, 0);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

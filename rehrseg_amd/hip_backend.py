@@ -415,13 +415,24 @@ def upmix_depth_fwd(g, bias, Do, Cc, KD, pd, act, slope):
     return y
 
 
-def upmix_depth_bwd(dz, Di, KD, pd):
-    _chk_dev(dz)
-    N, Cc, Do, H, W = dz.shape
-    dg = new_act(N, KD * Cc, Di, H, W, like=dz)
-    L.check(L.load().rehr_upmix_depth_bwd_f32(_ptr(dz), _ptr(dg), N, Di, Do, H * W, Cc, KD, pd, _stream()),
-            "rehr_upmix_depth_bwd_f32")
+def upmix_depth_bwd(dy, y, Di, KD, pd, act, slope):
+    """dg of upmix_depth_fwd from the output gradient dy and the saved output y (dz = dy * act'(y) on the fly)."""
+    _chk_dev(dy, y)
+    N, Cc, Do, H, W = dy.shape
+    dg = new_act(N, KD * Cc, Di, H, W, like=dy)
+    L.check(L.load().rehr_upmix_depth_bwd_f32(_ptr(dy), _ptr(y), _ptr(dg), N, Di, Do, H * W, Cc, KD, pd, act, slope,
+                                              _stream()), "rehr_upmix_depth_bwd_f32")
     return dg
+
+
+def channel_sum_actgrad(dy, y, act, slope):
+    _chk_dev(dy, y)
+    N, S, Cc = _nsc(dy)
+    out = torch.empty((Cc,), dtype=torch.float32, device=dy.device)
+    scratch = torch.empty((Cc,), dtype=torch.float64, device=dy.device)
+    L.check(L.load().rehr_channel_sum_actgrad_f32(_ptr(dy), _ptr(y), Cc, N * S, Cc, act, slope, _ptr(out), _ptr(scratch),
+                                                  _stream()), "rehr_channel_sum_actgrad_f32")
+    return out
 
 
 def window_stem_assemble(g, mean, bias, B, nwin, act, slope):

@@ -108,7 +108,8 @@ PROTOTYPES = {
     "rehr_upsample_depth_fwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "rehr_upsample_depth_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "rehr_upmix_depth_fwd_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _i32, C.c_float, _vp]),
-    "rehr_upmix_depth_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "rehr_upmix_depth_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _i32, C.c_float, _vp]),
+    "rehr_channel_sum_actgrad_f32": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),
     "rehr_cosdist_stats_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "rehr_cosdist_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, C.c_float, _vp]),
     "rehr_quad_maxpool_fwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),

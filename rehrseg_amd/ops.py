@@ -511,9 +511,9 @@ class _UpMixDepth(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         Di, KD, pd, act, slope, has_bias = ctx.cfg
         be = get_backend()
-        dz = to_cl(dy) if act == ACT_NONE else be.act_bwd(to_cl(dy), y, act, slope)
-        db = be.channel_sum(dz) if (has_bias and ctx.needs_input_grad[1]) else None
-        return be.upmix_depth_bwd(dz, Di, KD, pd), db, None, None, None, None, None, None
+        dy = to_cl(dy)
+        db = be.channel_sum_actgrad(dy, y, act, slope) if (has_bias and ctx.needs_input_grad[1]) else None
+        return be.upmix_depth_bwd(dy, y, Di, KD, pd, act, slope), db, None, None, None, None, None, None
 
 
 def upsample_conv3d_depth(x, w, b, scale, act=ACT_NONE, slope=0.0):

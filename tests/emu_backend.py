@@ -275,7 +275,12 @@ def upmix_depth_fwd(g, bias, Do, Cc, KD, pd, act, slope):
     return _act(y, act, slope).contiguous(memory_format=torch.channels_last_3d)
 
 
-def upmix_depth_bwd(dz, Di, KD, pd):
+def channel_sum_actgrad(dy, y, act, slope):
+    return (dy * _act_grad(y, act, slope)).sum(dim=(0, 2, 3, 4))
+
+
+def upmix_depth_bwd(dy, y, Di, KD, pd, act, slope):
+    dz = dy * _act_grad(y, act, slope)
     N, Cc, Do, H, W = dz.shape
     M = _upmix_w(Di, Do, KD, pd, dz.dtype)
     dg = torch.einsum("koj,ncohw->nkcjhw", M, dz).reshape(N, KD * Cc, Di, H, W)
