@@ -5,6 +5,10 @@ Pinned by tests/golden/aux_losses_teacher.npz (tools/gen_golden_losses.py ran th
   distiller_loss      models/seg_model.py:60-151
   bce_dice            utils/seg_utils.py:786-885
   robust_ce           utils/seg_utils.py:289-304 (incl. the (B,B,...) uncertainty broadcast, :349)
+  dc_and_weighted_ce  utils/seg_utils.py:306-351 as _build_loss (:353-357) configures it; the composition is pinned by
+                      tests/golden/seg_losses.npz (tools/gen_golden_segmodel.py ran the reference's forward over a
+                      stand-in for nnunetv2==2.3.1's MemoryEfficientSoftDiceLoss, which is absent offline: the
+                      soft-Dice formula itself stays PARITY UNPINNED)
   zscore              utils/seg_utils.py:137-149 (in place)
   teacher_features    train_all.py:85-112 (one window at a time, like the reference)
 """
@@ -52,6 +56,22 @@ def robust_ce(logits, target, uncertainty=None):
     if uncertainty is not None:
         loss = loss * uncertainty                                        # (B,1,D,H,W) -> broadcast (B,B,D,H,W)
     return loss.mean()
+
+
+def soft_dice(logits, target, smooth=1e-5, do_bg=False):
+    """nnunetv2 MemoryEfficientSoftDiceLoss (batch_dice=False), restated -- unpinned third-party formula."""
+    p = torch.softmax(logits, 1)
+    onehot = F.one_hot(target[:, 0].long(), logits.shape[1]).movedim(-1, 1).to(p.dtype)
+    if not do_bg:
+        p, onehot = p[:, 1:], onehot[:, 1:]
+    axes = tuple(range(2, p.ndim))
+    dc = (2 * (p * onehot).sum(axes) + smooth) / torch.clip(onehot.sum(axes) + p.sum(axes) + smooth, 1e-8)
+    return -dc.mean()
+
+
+def dc_and_weighted_ce(logits, target, uncertainty=None, weight_ce=1.0, weight_dice=1.0):
+    """target (B,1,D,H,W) float labels; uncertainty (B,1,D,H,W) or None."""
+    return weight_ce * robust_ce(logits, target[:, 0], uncertainty) + weight_dice * soft_dice(logits, target)
 
 
 def zscore(image):

@@ -1,4 +1,4 @@
-"""Functional CPU restatement of SegModel (TEST INFRASTRUCTURE) -- PARITY UNPINNED.
+"""Functional CPU restatement of SegModel (TEST INFRASTRUCTURE) -- in-reference parts PINNED, bases UNPINNED.
 
 In-reference parts followed: models/seg_model.py:26-58 (MyUnetDecoder.forward),
 :174-210 (SegModel: sr_head, depth-only trilinear upsample align_corners=True).
@@ -8,7 +8,12 @@ train_all.py:474-493), which is absent offline and not vendored; its published
 block semantics are restated: per stage n_conv x [Conv3d(k, pad=(k-1)//2, stride on
 the first conv) -> InstanceNorm3d(eps, affine) -> LeakyReLU(0.01)], decoder stage =
 ConvTranspose3d(kernel=stride) -> cat(skip) -> conv blocks, 1x1x1 seg layers.
-The reference ships no test or fixture for this boundary, so nothing can pin it.
+The reference ships no test or fixture for that package boundary, so the BASES stay
+"parity unpinned".  The parts the reference itself defines are pinned: tools/gen_golden_segmodel.py
+imports the reference's models/seg_model.py over eager-torch stand-ins for the two absent modules and
+records its SegModel.forward / MyUnetDecoder.forward outputs, losses and gradients
+(tests/golden/segmodel_{small,aniso4}.npz); this oracle and the HIP SegModel are checked against them
+(tests/test_segmodel_golden_cpu.py, tests/test_segmodel_golden_gpu.py).
 """
 import torch
 import torch.nn.functional as F
