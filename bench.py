@@ -43,19 +43,6 @@ def build_seg_model(dev):
                     nonlin=nn.LeakyReLU, nonlin_kwargs={"inplace": True}, deep_supervision=False).to(dev)
 
 
-class _Opt:
-    """optimizer facade whose zero_grad keeps PatchParallel's flat gradient views"""
-
-    def __init__(self, opt, pp):
-        self.opt, self.pp = opt, pp
-
-    def zero_grad(self):
-        self.pp.zero_grad()
-
-    def step(self):
-        self.opt.step()
-
-
 def cpu_baseline(size):
     """The oracle (a CPU port of the reference's path) on the host cores, one step."""
     from oracle import flavr_oracle as fo
@@ -146,7 +133,7 @@ def main():
         l1, bd = torch.nn.L1Loss(), BCEDiceLoss(1.0, 1.0)
 
         def step():
-            return train_sr_step(model, _Opt(opt, pp), None, x.clone(), hr, l1, bd, 4.0, 4, True,
+            return train_sr_step(model, opt, None, x.clone(), hr, l1, bd, 4.0, 4, True,
                                  grad_sync=pp.reduce_gradients)
     elif args.workload == "cfg4":
         # BASELINE.json configs[3]: the joint stage-2 step (train_all.py:519-556), 1 LR patch per GPU: frozen FLAVR
@@ -185,7 +172,7 @@ def main():
         l_lr, l_hr = _build_loss(False, weight_dice=0), _build_loss(False, weight_dice=1)
 
         def step():
-            return train_segsr_step(student, teacher, dist_m, _Opt(opt, pp), img.clone(), lab_lr, lab_hr, unc, l_lr, l_hr,
+            return train_segsr_step(student, teacher, dist_m, opt, img.clone(), lab_lr, lab_hr, unc, l_lr, l_hr,
                                     grad_sync=pp.reduce_gradients)
     else:
         model = build_seg_model(dev)

@@ -52,12 +52,18 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
 #pragma unroll
     for (int c = 0; c < C; ++c) aI[b][c] = aP[b][c] = aG[b][c] = 0.f;
   float ace = 0.f;
+  // samples are taken SL_MAXN at a time (grid.y): the cross-sample term sum_v (sum_b ce_b)(sum_a u_a) splits over
+  // chunks of b, every chunk pairing its ce with the uncertainty sum over ALL samples
+  const int b0 = blockIdx.y * SL_MAXN;
+  const int nb = (N - b0 < SL_MAXN) ? N - b0 : SL_MAXN;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < S; v += (int64_t)gridDim.x * blockDim.x) {
     float sce = 0.f, su = 0.f;
+    if (unc != nullptr)
+      for (int a = 0; a < N; ++a) su += unc[(int64_t)a * S + v];
 #pragma unroll
     for (int b = 0; b < SL_MAXN; ++b) {
-      if (b < N) {
-        const int64_t i = (int64_t)b * S + v;
+      if (b < nb) {
+        const int64_t i = (int64_t)(b0 + b) * S + v;
         const int t = (int)target[i];
         float p[C], ce;
         softmax_ce<C>(logits + i * ld, t, p, ce);
@@ -69,7 +75,6 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
           aP[b][c] += p[c];
           aG[b][c] += y;
         }
-        if (unc != nullptr) su += unc[i];
       }
     }
     ace += (unc != nullptr) ? sce * su : sce;
@@ -91,11 +96,11 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
   const float ce_ = wave_sum(ace);
   if (lane == 0) red[w][SL_MAXN * C * 3] = ce_;
   __syncthreads();
-  const int nstat = N * C * 3;
+  const int nstat = nb * C * 3;
   for (int k = threadIdx.x; k <= nstat; k += blockDim.x) {
     const int src = (k == nstat) ? SL_MAXN * C * 3 : k;
     const float s = red[0][src] + red[1][src] + red[2][src] + red[3][src];
-    atomicAdd(stats + k, (double)s);
+    atomicAdd(stats + ((k == nstat) ? N * C * 3 : b0 * C * 3 + k), (double)s);
   }
 }
 
@@ -109,9 +114,12 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
                                                            float* __restrict__ dlogits, int ldd) {
   // per (sample, class) Dice constants: d(-dc)/dp = -(2 y den - num) / den^2 = y*A + B
   __shared__ float cA[SL_MAXN * C], cB[SL_MAXN * C];
-  if (threadIdx.x < N * C) {
+  const int b0 = blockIdx.y * SL_MAXN;
+  const int nb = (N - b0 < SL_MAXN) ? N - b0 : SL_MAXN;
+  if (threadIdx.x < nb * C) {
     const int c = threadIdx.x % C;
-    const double I = stats[threadIdx.x * 3], P = stats[threadIdx.x * 3 + 1], G = stats[threadIdx.x * 3 + 2];
+    const double* sp = stats + (size_t)(b0 * C + threadIdx.x) * 3;
+    const double I = sp[0], P = sp[1], G = sp[2];
     const double num = 2.0 * I + smooth;
     const double raw = G + P + smooth;
     const double den = raw < 1e-8 ? 1e-8 : raw;
@@ -134,8 +142,8 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
     const float cw = kce * su;
 #pragma unroll
     for (int b = 0; b < SL_MAXN; ++b) {
-      if (b < N) {
-        const int64_t i = (int64_t)b * S + v;
+      if (b < nb) {
+        const int64_t i = (int64_t)(b0 + b) * S + v;
         const int t = (int)target[i];
         float p[C], ce;
         softmax_ce<C>(logits + i * ld, t, p, ce);
@@ -166,10 +174,10 @@ int grid_for(int64_t S) {
 extern "C" int rehr_seg_loss_fwd_f32(const float* logits, int32_t ld, const float* target, const float* unc,
                                      int32_t N, int32_t C, int64_t S, double* stats, void* stream) {
   if (!logits || !target || !stats || N < 1 || S < 1 || ld < C) return REHR_EINVAL;
-  if (N > SL_MAXN || C < 2 || C > 4) return REHR_ENOSUP;
+  if (C < 2 || C > 4 || N > 65535 * SL_MAXN) return REHR_ENOSUP;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(stats, 0, sizeof(double) * ((size_t)N * C * 3 + 1), st) != hipSuccess) return REHR_EHIP;
-  const dim3 g(grid_for(S)), t(256);
+  const dim3 g(grid_for(S), (N + SL_MAXN - 1) / SL_MAXN), t(256);
   if (C == 2) hipLaunchKernelGGL(seg_loss_fwd_kernel<2>, g, t, 0, st, logits, ld, target, unc, N, S, stats);
   else if (C == 3) hipLaunchKernelGGL(seg_loss_fwd_kernel<3>, g, t, 0, st, logits, ld, target, unc, N, S, stats);
   else hipLaunchKernelGGL(seg_loss_fwd_kernel<4>, g, t, 0, st, logits, ld, target, unc, N, S, stats);
@@ -183,9 +191,9 @@ extern "C" int rehr_seg_loss_bwd_f32(const float* logits, int32_t ld, const floa
                                      float* dlogits, int32_t ldd, void* stream) {
   if (!logits || !target || !stats || !grad_out || !dlogits || N < 1 || S < 1 || ld < C || ldd < C)
     return REHR_EINVAL;
-  if (N > SL_MAXN || C < 2 || C > 4) return REHR_ENOSUP;
+  if (C < 2 || C > 4 || N > 65535 * SL_MAXN) return REHR_ENOSUP;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g(grid_for(S)), t(256);
+  const dim3 g(grid_for(S), (N + SL_MAXN - 1) / SL_MAXN), t(256);
 #define SL_BWD(C_)                                                                                            \
   hipLaunchKernelGGL(seg_loss_bwd_kernel<C_>, g, t, 0, st, logits, ld, target, unc, N, S, stats, w_ce, w_dice, \
                      smooth, do_bg, grad_out, dlogits, ldd)

@@ -93,14 +93,21 @@ def _taps(t):
     return L.AxisTaps(*t)
 
 
-def _chk_dev(*ts):
+def _chk_dev(*ts, f64=()):
+    """Every operand of the fp32 kernels must be a float32 device tensor; `f64` lists the statistics buffers
+    (double accumulators) of the call."""
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise L.RehrsegHipError("librehrseg_hip.so needs device tensors (no CPU fallback)")
-        if t.dtype not in (torch.float32, torch.float64):
-            raise L.RehrsegHipError(f"unsupported dtype {t.dtype}")
+        if t.dtype != torch.float32:
+            raise L.RehrsegHipError(f"unsupported dtype {t.dtype} (the kernels read float32)")
+    for t in f64:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float64:
+            raise L.RehrsegHipError("statistics buffers are float64 device tensors")
 
 
 def new_act(N, Cc, D, H, W, like, zero=False):
@@ -125,7 +132,7 @@ wino_launches = 0  # contractions handed to the Winograd kernels so far (tests l
 
 def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad, y, y_dims, Cout,
              os_, ob, bias, act, slope, stats, stats_mode, tile):
-    _chk_dev(x1, x2, wp, y, bias, stats)
+    _chk_dev(x1, x2, wp, y, bias, f64=(stats,))
     d.x1, d.x2, d.c1 = _ptr(x1), _ptr(x2), c1
     d.ldx1 = x1.shape[1]
     d.ldx2 = x2.shape[1] if x2 is not None else 0
@@ -190,7 +197,7 @@ def gather_gemm_multi(calls):
 def sum_slabs_bias_act(slabs, S, bias, act, slope, stats=None):
     """slabs: (S*N, C, D, H, W) NDHWC partial results -> (N, C, D, H, W) = act(bias + sum over S);
     `stats` (N, C, 2) double, pre-zeroed: also accumulate the per-(n,c) sum / sum of squares."""
-    _chk_dev(slabs, bias, stats)
+    _chk_dev(slabs, bias, f64=(stats,))
     SN, Cc, D, H, W = slabs.shape
     N = SN // S
     y = new_act(N, Cc, D, H, W, like=slabs)
@@ -251,7 +258,7 @@ def _direct_desc(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
 
 
 def small_cin_fwd(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
-    _chk_dev(x, w, bias, y, stats)
+    _chk_dev(x, w, bias, y, f64=(stats,))
     d = _direct_desc(x, w.contiguous(), bias, y, stride, pad, act, slope, stats, stats_mode)
     L.check(L.load().rehr_conv_small_cin_fwd_f32(C.byref(d), _stream()), "rehr_conv_small_cin_fwd_f32")
 
@@ -311,7 +318,7 @@ def small_cout_wgrad(x, w, dy, pad, want_bias):
 
 
 def se_gate_fwd(stats, w, b, N, Cc, S):
-    _chk_dev(stats, w, b)
+    _chk_dev(w, b, f64=(stats,))
     gate = torch.empty((N, Cc), dtype=torch.float32, device=stats.device)
     mean = torch.empty((N, Cc), dtype=torch.float32, device=stats.device)
     L.check(L.load().rehr_se_gate_fwd_f32(_ptr(stats), _ptr(w.contiguous()), _ptr(b.contiguous()), _ptr(gate),
@@ -346,7 +353,7 @@ def scale_res_act_bwd(dy, y, x, gate, want_dres, act, slope):
 
 
 def se_gate_bwd(dgate, gate, mean, w, S):
-    _chk_dev(dgate, gate, mean, w)
+    _chk_dev(gate, mean, w, f64=(dgate,))
     N, Cc = gate.shape
     dw = torch.empty((Cc, Cc), dtype=torch.float32, device=gate.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=gate.device)
@@ -364,7 +371,7 @@ def add_channel_const(x, k):
 
 
 def instnorm_act_fwd(x, stats, gamma, beta, eps, act, slope):
-    _chk_dev(x, stats, gamma, beta)
+    _chk_dev(x, gamma, beta, f64=(stats,))
     N, S, Cc = _nsc(x)
     y = new_act(*x.shape, like=x)
     mr = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
@@ -459,7 +466,7 @@ def cosdist_stats(x1, x2):
 
 
 def cosdist_bwd(x1, x2, stats, scale):
-    _chk_dev(x1, x2, stats)
+    _chk_dev(x1, x2, f64=(stats,))
     N, Cc, D, H, W = x1.shape
     dx = new_act(N, Cc, D, H, W, like=x1)
     L.check(L.load().rehr_cosdist_bwd_f32(_ptr(x1), _ptr(x2), _ptr(stats), _ptr(dx), N, D * H * W, Cc, float(scale),
@@ -525,7 +532,7 @@ def seg_loss_fwd(logits, target, unc):
 
 
 def seg_loss_bwd(logits, target, unc, stats, w_ce, w_dice, smooth, do_bg, grad_out):
-    _chk_dev(logits, target, unc, stats, grad_out)
+    _chk_dev(logits, target, unc, grad_out, f64=(stats,))
     N, Cc, D, H, W = logits.shape
     dl = new_act(N, Cc, D, H, W, like=logits)
     L.check(L.load().rehr_seg_loss_bwd_f32(_ptr(logits), Cc, _ptr(target), _ptr(unc), N, Cc, D * H * W, _ptr(stats),

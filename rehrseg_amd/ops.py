@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import functools
 import itertools
+import weakref
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -320,19 +321,48 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
 
 
 # Parameters whose .grad is a view into a caller-owned flat buffer (rehrseg_amd.parallel.PatchParallel):
-# weight.data_ptr() -> (parameter, owner).  The weight-gradient kernels then write straight into that view
-# and the owner is told the gradient is ready, instead of returning a temporary for autograd to add into it
-# (one extra elementwise pass and one allocation per parameter and step).
+# weight.data_ptr() -> (weakref(parameter), weakref(owner)).  The weight-gradient kernels then write straight
+# into that view and the owner is told the gradient is ready, instead of returning a temporary for autograd to
+# add into it (one extra elementwise pass and one allocation per parameter and step).  Weak references: a
+# registry entry never keeps a model alive, and an address reused by another tensor does not match a dead one.
 _direct_grad = {}
 
 
-def _direct_grad_target(w):
+def register_direct_grad(param, owner):
+    _direct_grad[param.data_ptr()] = (weakref.ref(param), weakref.ref(owner))
+
+
+def unregister_direct_grad(owner):
+    for k in [k for k, (_, o) in _direct_grad.items() if o() is owner or o() is None]:
+        del _direct_grad[k]
+
+
+def _direct_entry(w):
     ent = _direct_grad.get(w.data_ptr())
+    if ent is None:
+        return None
+    param, owner = ent[0](), ent[1]()
+    if param is None or owner is None or param.data_ptr() != w.data_ptr() or param.shape != w.shape:
+        del _direct_grad[w.data_ptr()]
+        return None
+    return param, owner
+
+
+def _note_use(w):
+    """Forward of a node that will want this weight's gradient: the owner counts the uses per step, a weight
+    used more than once keeps autograd's accumulation (a direct write would be overwritten by the next use)."""
+    ent = _direct_entry(w)
+    if ent is not None:
+        ent[1].note_use(ent[0])
+
+
+def _direct_grad_target(w):
+    ent = _direct_entry(w)
     if ent is None:
         return None
     param, owner = ent
     g = param.grad
-    if g is None or g.shape != w.shape or not g.is_contiguous() or owner.was_written(param):
+    if g is None or g.shape != w.shape or not g.is_contiguous() or not owner.may_write(param):
         return None
     return param, owner, g
 
@@ -424,6 +454,8 @@ class _FusedConv(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has = (x2 is not None, b is not None, res is not None)
         ctx.save_for_backward(x1, x2, w, p1, p2, y0, y, gate, mean, mr)
+        if _direct_grad and ctx.needs_input_grad[2]:
+            _note_use(w)
         return y
 
     @staticmethod

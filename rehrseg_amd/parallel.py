@@ -8,9 +8,20 @@ into it), laid out in REVERSE registration order: backward produces the decoder'
 gradients first, so the front of the buffer completes first.  The buffer is cut into
 a few large buckets (default 64 MiB: xGMI is point-to-point and per-link bound, so
 few large messages beat many small ones); a bucket's all-reduce is launched from a
-post-accumulate hook the moment its last gradient has been written, i.e. the exchange
+post-accumulate hook the moment its last gradient is complete, i.e. the exchange
 of the decoder's gradients overlaps the encoder's backward.  No flatten/unflatten
 copies, no per-parameter messages.
+
+A gradient reaches its slot by one of three routes:
+  direct   conv weights on the device: the weight-gradient kernel writes into the slot itself
+           (rehrseg_amd.ops registers them; only for weights used once in a step)
+  stolen   small parameters get `.grad = None` at zero_grad, autograd hands over a fresh tensor
+           (no add kernel), the values are copied into the slot bucket-wise right before the exchange
+  in place autograd accumulates into the view (weights used several times, or after a plain
+           `optimizer.zero_grad(set_to_none=False)`)
+and whatever `.grad` holds when a bucket is exchanged is reconciled with the slot (`_collect`): a tensor that
+is not the view is copied in and the view restored, a missing gradient contributes zeros -- so a plain
+`optimizer.zero_grad()` (set_to_none=True) between steps is safe too.
 """
 from __future__ import annotations
 
@@ -19,7 +30,12 @@ import torch.distributed as dist
 
 
 class PatchParallel:
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 64, process_group=None, overlap: bool = True):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 64, process_group=None, overlap: bool = True,
+                 force_overlap: bool = False, direct=None):
+        """force_overlap: take the hook-launched bucket path even with a single rank (tests: the exchange code
+        then runs, over a world-1 group, exactly as it does on 8 GPUs).
+        direct: the parameters whose gradient the weight-gradient kernels may write in place (default: every
+        5-D device parameter, i.e. the conv weights)."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -32,36 +48,36 @@ class PatchParallel:
         bucket_elems = max(1, int(bucket_mb * (1 << 20)) // self.flat.element_size())
         # reverse registration order ~ the order in which backward finishes the gradients
         self._bucket_of = {}
-        self.buckets = []  # [start, end, n_params]
+        self.buckets = []  # [start, end]
+        self._params_of_bucket = []
+        self._view = {}
         off = 0
         for p in reversed(self.params):
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self._view[id(p)] = p.grad = self.flat[off:off + n].view_as(p)
             if not self.buckets or off - self.buckets[-1][0] >= bucket_elems:
-                self.buckets.append([off, off + n, 0])
-            b = self.buckets[-1]
-            b[1] = off + n
-            b[2] += 1
-            self._bucket_of[p] = len(self.buckets) - 1
+                self.buckets.append([off, off + n])
+                self._params_of_bucket.append([])
+            self.buckets[-1][1] = off + n
+            self._params_of_bucket[-1].append(p)
+            self._bucket_of[id(p)] = len(self.buckets) - 1
             off += n
         # conv weights: let the weight-gradient kernels write into the flat buffer directly (rehrseg_amd.ops)
         from . import ops
-        self._written = set()
-        for p in self.params:
-            if p.dim() == 5 and p.is_cuda:
-                ops._direct_grad[p.data_ptr()] = (p, self)
+        self._ops = ops
+        self._direct = [p for p in self.params if p.dim() == 5 and p.is_cuda] if direct is None else list(direct)
+        for p in self._direct:
+            ops.register_direct_grad(p, self)
         # every other parameter (biases, norm / gate parameters: dozens of tiny tensors) gets `.grad = None` at
         # zero_grad, so autograd hands its gradient over without an add kernel each (0.7-1.0 ms of 10 us launches
         # per step); the values are copied into the flat buffer bucket-wise, right before a bucket's exchange
-        self._steal = [p for p in self.params if not (p.dim() == 5 and p.is_cuda)]
-        self._view = {id(p): p.grad for p in self._steal}
-        self._steal_of_bucket = [[] for _ in self.buckets]
-        for p in self._steal:
-            self._steal_of_bucket[self._bucket_of[p]].append(p)
-        self.overlap = overlap and self.world > 1
-        self._pending = [b[2] for b in self.buckets]
-        self._works = []
-        self._launched = [False] * len(self.buckets)
+        direct_ids = {id(p) for p in self._direct}
+        self._steal = [p for p in self.params if id(p) not in direct_ids]
+        self.exchange = self.world > 1 or force_overlap
+        if force_overlap and not dist.is_initialized():
+            raise ValueError("force_overlap needs an initialised process group (world size 1 is fine)")
+        self.overlap = overlap and self.exchange
+        self._reset_step()
         if self.overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
@@ -71,28 +87,56 @@ class PatchParallel:
             for b in module.buffers():
                 dist.broadcast(b.data, src=0, group=process_group)
 
+    def _reset_step(self):
+        self._written = set()                                   # ids of parameters a kernel wrote directly
+        self._uses = {}                                         # id -> forward uses in this step
+        self._ready = [set() for _ in self.buckets]             # per bucket: ids whose gradient is complete
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def close(self):
+        """Drop the registrations in rehrseg_amd.ops (also happens by itself when this object dies)."""
+        self._ops.unregister_direct_grad(self)
+
     # ------------------------------------------------------------------ bucket exchange
     def _collect(self, i):
-        """Bucket i's handed-over gradients -> their slots of the flat buffer; `.grad` becomes the view again."""
-        ps = [p for p in self._steal_of_bucket[i] if p.grad is not None and p.grad is not self._view[id(p)]]
-        if ps:
-            torch._foreach_copy_([self._view[id(p)] for p in ps], [p.grad for p in ps])
-            for p in ps:
-                p.grad = self._view[id(p)]
+        """Reconcile bucket i's slots with what `.grad` holds; afterwards every `.grad` is its view again."""
+        src, dst, zero = [], [], []
+        for p in self._params_of_bucket[i]:
+            v = self._view[id(p)]
+            if p.grad is None:
+                if id(p) not in self._written:
+                    zero.append(v)                              # no gradient this step: contributes zeros
+            elif p.grad is not v:
+                src.append(p.grad)
+                dst.append(v)
+            p.grad = v
+        if zero:
+            torch._foreach_zero_(zero)
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def _launch(self, i):
-        s, e, _ = self.buckets[i]
+        s, e = self.buckets[i]
         self._collect(i)
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._launched[i] = True
 
     def _on_grad_ready(self, p):
-        i = self._bucket_of[p]
-        self._pending[i] -= 1
-        if self._pending[i] == 0 and not self._launched[i]:
+        i = self._bucket_of[id(p)]
+        self._ready[i].add(id(p))                               # idempotent: a parameter counts once
+        if len(self._ready[i]) == len(self._params_of_bucket[i]) and not self._launched[i]:
             self._launch(i)
 
     # ---- direct gradient writes (see rehrseg_amd.ops._direct_grad)
+    def note_use(self, p):
+        self._uses[id(p)] = self._uses.get(id(p), 0) + 1
+
+    def may_write(self, p):
+        """A kernel may overwrite p.grad only if this is the weight's single use in the step and nothing
+        has been written yet (otherwise autograd's accumulation is the only correct route)."""
+        return self._uses.get(id(p), 0) == 1 and id(p) not in self._written
+
     def was_written(self, p):
         return id(p) in self._written
 
@@ -103,31 +147,32 @@ class PatchParallel:
             self._on_grad_ready(p)
 
     def zero_grad(self):
-        """Keeps the .grad views (optimizer.zero_grad(set_to_none=True) would drop them)."""
+        """Keeps the .grad views of the conv weights, hands the small parameters' `.grad` to autograd."""
         self.flat.zero_()
+        for p in self._direct:
+            p.grad = self._view[id(p)]
         for p in self._steal:
             p.grad = None
-        self._written.clear()
-        self._pending = [b[2] for b in self.buckets]
-        self._launched = [False] * len(self.buckets)
-        self._works = []
+        self._reset_step()
 
     def reduce_gradients(self):
         """Sum over ranks, divide by world size; returns after the exchange completed.
         Buckets whose hooks did not fire (parameters without a gradient this step, or
-        overlap disabled) are exchanged here."""
-        if self.world == 1:
-            return  # (handed-over gradients stay where autograd put them: the optimizer reads p.grad)
+        overlap disabled) are exchanged here.  Ends the step's bookkeeping, so the next backward
+        starts clean whether or not `zero_grad()` of this object is called in between."""
+        if not self.exchange:
+            # single rank: handed-over gradients stay where autograd put them (the optimizer reads p.grad)
+            self._written.clear()
+            self._uses.clear()
+            return
         for i in range(len(self.buckets)):
             if not self._launched[i]:
                 self._launch(i)
         for w in self._works:
             w.wait()
-        self._works = []
-        self.flat.div_(self.world)
-        for p in self._steal:  # parameters without a gradient this step: back to the (zero) view, like before
-            if p.grad is None:
-                p.grad = self._view[id(p)]
+        if self.world > 1:
+            self.flat.div_(self.world)
+        self._reset_step()
 
     def grad_bytes(self):
         return self.flat.numel() * self.flat.element_size()

@@ -54,9 +54,24 @@ def get_intermediate_features(model_sr, img_lr, label_lr, device=None, levels=No
     return out
 
 
+def _zero_grad(opt, grad_sync, zero_grad):
+    """`opt.zero_grad()` of the reference loops.  With patch-parallel training (grad_sync =
+    PatchParallel.reduce_gradients) the wrapper's own zero_grad is used: it keeps the conv weights' `.grad`
+    views into the flat exchange buffer, so their gradients are written in place instead of re-allocated.
+    (A plain optimizer.zero_grad() stays correct -- PatchParallel reconciles at the exchange -- just slower.)"""
+    if zero_grad is not None:
+        return zero_grad()
+    owner = getattr(grad_sync, "__self__", None)
+    if owner is not None and callable(getattr(owner, "zero_grad", None)) and hasattr(owner, "reduce_gradients"):
+        return owner.zero_grad()
+    return opt.zero_grad()
+
+
 def train_sr_step(model, opt, scheduler, patches_lr, patches_hr, loss_obj, loss_seg, slice_separation, num_slices,
-                  enable_uncertainty, grad_sync=None):
-    """One iteration of train_sr's inner loop (train_all.py:118-139); returns the loss tensor."""
+                  enable_uncertainty, grad_sync=None, zero_grad=None):
+    """One iteration of train_sr's inner loop (train_all.py:118-139); returns the loss tensor.
+    grad_sync: called between backward and the optimizer step (PatchParallel.reduce_gradients);
+    zero_grad: overrides how gradients are cleared (default: see _zero_grad)."""
     if num_slices > 1:
         s = int(slice_separation)
         patches_hr = patches_hr[:, :, s * (num_slices // 2 - 1):s * (num_slices // 2), ...]
@@ -69,7 +84,7 @@ def train_sr_step(model, opt, scheduler, patches_lr, patches_hr, loss_obj, loss_
         hat = model(patches_lr)
         loss = loss_obj(hat[:, 0:1], patches_hr[:, 0:1])
     loss = loss + loss_seg(hat[:, 1:], patches_hr[:, 1:]) * 1.0
-    opt.zero_grad()
+    _zero_grad(opt, grad_sync, zero_grad)
     loss.backward()
     if grad_sync is not None:
         grad_sync()
@@ -80,7 +95,7 @@ def train_sr_step(model, opt, scheduler, patches_lr, patches_hr, loss_obj, loss_
 
 
 def train_segsr_step(model_seg, model_sr, distiller, opt, img, label_lr, label_hr, uncertainty_lr, loss_lr_seg,
-                     loss_hr_seg, enable_uncertainty=True, teacher_levels=(1,), grad_sync=None):
+                     loss_hr_seg, enable_uncertainty=True, teacher_levels=(1,), grad_sync=None, zero_grad=None):
     """One iteration of the stage-2 loop (train_all.py:521-556); returns the loss tensor."""
     model_seg.train()
     if distiller is not None:
@@ -95,7 +110,7 @@ def train_segsr_step(model_seg, model_sr, distiller, opt, img, label_lr, label_h
         loss = loss_lr_seg(seg_lr, label_lr) + loss_hr_seg(seg_sr, label_hr)
     if distiller is not None:
         loss = loss + distiller(features_seg[1], features_sr[1])
-    opt.zero_grad()
+    _zero_grad(opt, grad_sync, zero_grad)
     loss.backward()
     if grad_sync is not None:
         grad_sync()

@@ -126,6 +126,7 @@ class _FusedDCCE(torch.autograd.Function):
 
 class DC_and_weighted_CE_loss(nn.Module):
     """ref :306-351: weight_ce * CE(uncertainty-weighted) + weight_dice * soft Dice."""
+    _warned = False
 
     def __init__(self, soft_dice_kwargs, ce_kwargs, weight_ce=1, weight_dice=1, ignore_label=None,
                  dice_class=SoftDiceLoss):
@@ -136,18 +137,30 @@ class DC_and_weighted_CE_loss(nn.Module):
         self.ce = RobustCrossEntropyLoss(**ce_kwargs)
         self.dc = dice_class(apply_nonlin=softmax_helper_dim1, **soft_dice_kwargs)
 
-    def _fusable(self, net_output, target):
+    def _fusable(self, net_output, target, uncertainty):
+        """The fused kernel covers what the reference's stage-2 loop passes (train_all.py:538-548): 5-D logits with
+        2..4 classes, a (N,1,D,H,W) label map with values in [0, C) (precondition, unchecked: torch's CE would raise),
+        no ignore label, and an uncertainty map of exactly (N,1,D,H,W) -- the shape whose product with the (N,D,H,W)
+        loss map broadcasts across samples; any other uncertainty shape multiplies differently
+        in the reference and takes the composition below."""
         dc = self.dc
+        N = net_output.shape[0]
         return (net_output.is_cuda and net_output.dim() == 5 and self.ignore_label is None and
                 type(dc) is SoftDiceLoss and not dc.batch_dice and dc.apply_nonlin is softmax_helper_dim1 and
-                2 <= net_output.shape[1] <= 4 and net_output.shape[0] <= 4 and
+                2 <= net_output.shape[1] <= 4 and target.dim() == 5 and target.shape[1] == 1 and
                 target.numel() == net_output.numel() // net_output.shape[1] and
+                (uncertainty is None or tuple(uncertainty.shape) == (N, 1) + tuple(net_output.shape[2:])) and
                 self.ce.weight is None and self.ce.label_smoothing == 0.0)
 
     def forward(self, net_output, target, uncertainty=None):
-        if self._fusable(net_output, target):  # device tensors: one HIP pass (no torch composition on the GPU)
+        if self._fusable(net_output, target, uncertainty):  # device tensors: one HIP pass each way
             return _FusedDCCE.apply(net_output, target, uncertainty, float(self.weight_ce), float(self.weight_dice),
                                     float(self.dc.smooth), bool(self.dc.do_bg))
+        if net_output.is_cuda and not DC_and_weighted_CE_loss._warned:
+            DC_and_weighted_CE_loss._warned = True
+            import warnings
+            warnings.warn("DC_and_weighted_CE_loss: configuration outside the fused HIP kernel (classes > 4, ignore label, "
+                          "class weights or an unusual target / uncertainty shape): composed from torch ops on the device")
         if self.ignore_label is not None:
             assert target.shape[1] == 1
             mask = target != self.ignore_label

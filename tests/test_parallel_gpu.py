@@ -33,8 +33,8 @@ def test_direct_gradient_writes_equal_autograd_accumulation():
     pp.zero_grad()
     for _ in range(2):
         m(x.clone()).abs().mean().backward()
-    pp.reduce_gradients()
     assert len(pp._written) >= 20                        # the conv weights really took the direct path
+    pp.reduce_gradients()
     for n, p in m.named_parameters():
         if n not in want:
             continue
@@ -48,3 +48,70 @@ def test_direct_gradient_writes_equal_autograd_accumulation():
             continue
         scale = float(want[n].abs().max()) + 1e-30
         assert float((p.grad - want[n] / 2).abs().max()) <= 2e-5 * scale, n
+
+
+OVERLAP_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)          # RCCL communicator first, then the kernels
+from oracle.detinit import det_tensor
+from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+from rehrseg_amd.parallel import PatchParallel
+dev = torch.device("cuda:0")
+def model():
+    m = UNet_3D_3D(2, "unet_18", 4, 4)
+    m.load_state_dict({{k: det_tensor(k, tuple(v.shape)) for k, v in m.state_dict().items()}})
+    return m.to(dev)
+g = torch.Generator().manual_seed(2)
+x = torch.rand(2, 2, 4, 32, 32, generator=g).to(dev)
+ref = model()
+ref(x.clone()).abs().mean().backward()
+want = {{n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}}
+m = model()
+pp = PatchParallel(m, bucket_mb=16, force_overlap=True)        # ~10 buckets, launched from hooks during backward
+assert pp.overlap and pp.exchange and len(pp.buckets) >= 8
+worst, launched_in_backward, written = 0.0, [], []
+for step in range(3):
+    if step == 1:
+        torch.optim.SGD(m.parameters(), lr=0.0).zero_grad()     # plain zero_grad(set_to_none=True) in between
+    else:
+        pp.zero_grad()
+    m(x.clone()).abs().mean().backward()
+    launched_in_backward.append(sum(pp._launched))
+    written.append(len(pp._written))
+    pp.reduce_gradients()
+    for n, p in m.named_parameters():
+        if n in want:
+            worst = max(worst, float((p.grad - want[n]).abs().max()) / (float(want[n].abs().max()) + 1e-30))
+        else:
+            assert float(p.grad.abs().max()) == 0.0, n          # parameters outside the graph: zeros
+torch.cuda.synchronize()
+print("RESULT " + json.dumps({{"worst": worst, "launched": launched_in_backward, "written": written,
+                              "buckets": len(pp.buckets)}}))
+dist.destroy_process_group()
+"""
+
+
+def test_hook_launched_buckets_with_direct_writes_under_rccl_world1(tmp_path):
+    """The multi-rank code path on the device: post-accumulate hooks + direct weight-gradient writes launch the
+    bucket all-reduces (RCCL, world-1 group) DURING backward; the result equals plain autograd.  Fresh
+    interpreter: the communicator is created before any kernel of the library runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", OVERLAP_SCRIPT.format(root=root)], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["worst"] <= 2e-5, res
+    # every bucket whose parameters all received a gradient went out from a hook before reduce_gradients
+    assert min(res["launched"]) >= res["buckets"] - 2, res
+    assert res["written"][0] >= 20 and res["written"][1] == 0 and res["written"][2] >= 20, res
