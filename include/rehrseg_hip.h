@@ -153,7 +153,13 @@ typedef struct {
   float* workspace;                /* >= rehr_wgrad_workspace_bytes() */
   int64_t workspace_bytes;
   float* dbias;                    /* NULL or [Ca]: dbias[a] (+)= sum l[...,a] */
+  int32_t flags;                   /* REHR_WGRAD_* bits; 0 = let the library pick the kernel */
 } rehr_wgrad_desc;
+
+/* flags: force the direct (slab / brick) kernels even where a transform-domain (Winograd) kernel applies.
+ * Everything that selects a kernel travels in the descriptors: the library reads no environment
+ * variables and keeps no mutable state between calls. */
+#define REHR_WGRAD_DIRECT 1
 
 int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* d);
 /* 1 when rehr_wgrad_f32 will take the Winograd path for this descriptor (unit stride,

@@ -1160,13 +1160,8 @@ extern "C" int rehr_conv_small_cout_wgrad_f32(const rehr_direct_conv_desc* dp, f
     const int64_t rows_floats = (int64_t)(HB_D + d.KD - 1) * (HB_H + d.KH - 1) * ((HB_W + 4) * d.Cin + 16) + HB_VOX * 2;
     if (CO == 2 && d.KW == 5 && d.KH == 5 && d.KD == 5 && d.Cin == 16 && rows_floats * 4 <= 64 * 1024 &&
         (HB_D + d.KD - 1) * (HB_H + d.KH - 1) * (HB_W + 4) * (d.Cin / 4) <= BRK_MAXP * 256) {
-      static const bool old_kernel = getenv("REHR_THIN_WGRAD_OLD") != nullptr;  // A/B switch for benchmarking
-      if (!old_kernel) {
-        hipLaunchKernelGGL(small_cout2_wgrad_rows_kernel<5>, dim3(hblocks), dim3(256), (size_t)rows_floats * 4, st, d,
-                           workspace, bpb, nbd, nbh, nbw);
-      } else
-        hipLaunchKernelGGL(small_cout_wgrad_halo_kernel<2>, dim3(hblocks), dim3(256), hsmem, st, d, workspace, bpb, nbd,
-                           nbh, nbw);
+      hipLaunchKernelGGL(small_cout2_wgrad_rows_kernel<5>, dim3(hblocks), dim3(256), (size_t)rows_floats * 4, st, d,
+                         workspace, bpb, nbd, nbh, nbw);
     } else if (CO == 2)
       hipLaunchKernelGGL(small_cout_wgrad_halo_kernel<2>, dim3(hblocks), dim3(256), hsmem, st, d, workspace, bpb, nbd,
                          nbh, nbw);

@@ -304,9 +304,6 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
 }
 
 bool plan22(const rehr_gather_gemm_desc& d, W22Params& p) {
-  const char* env22 = getenv("REHR_WINO22");  // read per call: tests switch the path at run time
-  const bool off = env22 && env22[0] == '0';
-  if (off) return false;
   if (d.sd != 1) return false;
   AxisPlan ah, aw;
   if (!plan_axis(d.th, d.sh, d.bh, ah) || !plan_axis(d.tw, d.sw, d.bw, aw)) return false;

@@ -248,9 +248,7 @@ __global__ void wino22_wgrad_reduce_kernel(const WW22Params p) {
 }
 
 bool plan(const rehr_wgrad_desc& d, WW22Params& p) {
-  const char* env22 = getenv("REHR_WINO22");  // read per call: tests switch the path at run time
-  const bool off = env22 && env22[0] == '0';
-  if (off || d.dbias != nullptr) return false;
+  if ((d.flags & REHR_WGRAD_DIRECT) || d.dbias != nullptr) return false;
   if (d.sd != 1) return false;
   AxisPlan ah, aw;
   if (!plan_axis(d.th, d.sh, d.bh, ah) || !plan_axis(d.tw, d.sw, d.bw, aw)) return false;

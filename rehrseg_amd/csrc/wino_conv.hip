@@ -997,7 +997,6 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   if (!d.wino_ws) return REHR_ENOSUP;
   const int64_t need = wino_workspace_bytes(d);
   if (need == 0 || d.wino_ws_bytes < need || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;
-  static const bool no_big = getenv("REHR_WINO_SMALL") != nullptr;  // A/B switch for benchmarking
   WinoParams p;
   p.d = d;
   p.kchunks = (d.Cin + 31) / 32;
@@ -1006,7 +1005,7 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   p.up = d.wino_ws;
   p.up_bytes = (uint32_t)need;
   p.nsplit = 0;
-  if (w32_ok(d) && !no_big) {
+  if (w32_ok(d)) {
     const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -1028,7 +1027,7 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     REHR_LAUNCH_CHECK();
     return REHR_OK;
   }
-  if (big_ok(d) && !no_big) {
+  if (big_ok(d)) {
     const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -472,9 +472,7 @@ bool three_taps_w(const rehr_axis_taps& t, int b) {
 }
 
 bool plan(const rehr_wgrad_desc& d, WWParams& p) {
-  const char* envw = getenv("REHR_WINO_WGRAD");  // read per call: tests switch the path at run time
-  const bool off = envw && envw[0] == '0';
-  if (off) return false;
+  if (d.flags & REHR_WGRAD_DIRECT) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (!three_taps_w(d.th, d.bh) || !three_taps_w(d.tw, d.bw)) return false;
   if (d.td.count < 1 || d.td.count > 256) return false;  // any number of depth taps (feature_fuse: 128): one grid.z each

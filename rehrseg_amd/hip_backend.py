@@ -124,8 +124,11 @@ def pack_weights(w, A, Apad, B, T, transpose):
     return out
 
 
-# Winograd F(2x2,3x3) over (H,W) for unit-stride 3x3 taps (REHR_WINOGRAD=0 switches it off)
-USE_WINOGRAD = os.environ.get("REHR_WINOGRAD", "1") != "0"
+# Kernel selection travels in the descriptors (the library reads no environment): forward / input gradient take
+# the Winograd kernels when the descriptor carries scratch, the weight gradient unless flags has REHR_WGRAD_DIRECT.
+# Tests flip these to compare the transform-domain kernels with the direct ones.
+USE_WINOGRAD = True
+USE_WINOGRAD_WGRAD = True
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
 wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
 
@@ -227,6 +230,7 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     d.dst_sa, d.dst_sc, d.dst_st = dst_strides
     d.accumulate = int(accumulate)
     d.dbias = _ptr(dbias)
+    d.flags = 0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT
     lib = L.load()
     nbytes = lib.rehr_wgrad_workspace_bytes(C.byref(d))
     if nbytes < 0:

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "librehrseg_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rehrseg_hip.h")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
+WGRAD_DIRECT = 1  # rehr_wgrad_desc.flags
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p
@@ -60,6 +61,7 @@ class WgradDesc(C.Structure):
         ("accumulate", _i32),
         ("workspace", _vp), ("workspace_bytes", _i64),
         ("dbias", _vp),
+        ("flags", _i32),
     ]
 
 

@@ -25,19 +25,17 @@ pytestmark = pytest.mark.gpu
 
 class direct_kernels:
     """Run with every Winograd path switched off (forward/dgrad via the scratch switch, wgrad via the
-    library's per-call environment switches)."""
+    descriptor's REHR_WGRAD_DIRECT flag)."""
 
     def __enter__(self):
         from rehrseg_amd import hip_backend
         self.hb, self.prev = hip_backend, hip_backend.USE_WINOGRAD
         hip_backend.USE_WINOGRAD = False
-        os.environ["REHR_WINO_WGRAD"] = "0"
-        os.environ["REHR_WINO22"] = "0"
+        hip_backend.USE_WINOGRAD_WGRAD = False
 
     def __exit__(self, *a):
         self.hb.USE_WINOGRAD = self.prev
-        os.environ.pop("REHR_WINO_WGRAD")
-        os.environ.pop("REHR_WINO22")
+        self.hb.USE_WINOGRAD_WGRAD = True
 
 
 def _grads(model, loss_fn):

@@ -12,9 +12,8 @@ for D in (8, 128):
     y = f(); g = torch.randn_like(y)
     res = {}
     for mode in ("0", "1"):
-        os.environ["REHR_WINOGRAD"] = mode
         hip_backend.USE_WINOGRAD = mode == "1"
-        os.environ["REHR_WINO_WGRAD"] = mode
+        hip_backend.USE_WINOGRAD_WGRAD = mode != "0"
         y = f()
         gr = torch.autograd.grad(y, [x, w, b], g)
         res[mode] = [y] + list(gr)

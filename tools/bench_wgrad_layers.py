@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from rehrseg_amd import ops
+from rehrseg_amd import hip_backend, ops
 dev = torch.device("cuda:0")
 shapes = [(2, 64, 32, 128, 128, 128), (2, 32, 64, 64, 64, 64), (2, 32, 16, 256, 128, 128), (2, 128, 64, 64, 64, 64), (2, 256, 256, 16, 16, 16),
           (1, 64, 64, 128, 64, 64), (1, 128, 128, 128, 32, 32), (1, 512, 512, 128, 16, 16), (2, 32, 32, 128, 128, 128),
@@ -12,9 +12,9 @@ for (N, Cin, Cout, D, H, W) in shapes:
     dz = torch.randn(N, Cout, D, H, W, device=dev).contiguous(memory_format=torch.channels_last_3d)
     w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) * 0.02
     cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
-    os.environ["REHR_WINO_WGRAD"] = "0"
+    hip_backend.USE_WINOGRAD_WGRAD = False
     ref, rb = ops.conv_wgrad(dz, x, None, w, cfg, True)
-    os.environ["REHR_WINO_WGRAD"] = "1"
+    hip_backend.USE_WINOGRAD_WGRAD = True
     got, gb = ops.conv_wgrad(dz, x, None, w, cfg, True)
     err = ((got - ref).abs().max() / ref.abs().max()).item()
     errb = ((gb - rb).abs().max() / rb.abs().max()).item()
