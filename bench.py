@@ -43,32 +43,58 @@ def build_seg_model(dev):
                     nonlin=nn.LeakyReLU, nonlin_kwargs={"inplace": True}, deep_supervision=False).to(dev)
 
 
-def cpu_baseline(size):
-    """The oracle (a CPU port of the reference's path) on the host cores, one step."""
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo); logical count if unknown."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        return len(pairs) or os.cpu_count()
+    except OSError:
+        return os.cpu_count()
+
+
+def cpu_baseline(size, state_dict, x, tgt, timed=3):
+    """The oracle (a CPU port of the reference's path, oracle/flavr_oracle.py) on the host cores: the SAME weights,
+    input and target as the GPU model, 1 warm-up + `timed` forward+backward steps, median.  Returns the record and
+    the warm-up step's (output, loss) for the parity line."""
     from oracle import flavr_oracle as fo
-    torch.manual_seed(0)
-    shapes = fo.flavr_shapes(1, size, 4)
-    sd = {}
-    for k, s in shapes.items():
-        t = torch.randn(s) * (0.02 if len(s) > 1 else 0.0)
-        sd[k] = t.requires_grad_()
-    x = torch.rand(1, 1, size, size, size)
-    tgt = torch.rand(1, 1, 4, size, size)
-    t0 = time.perf_counter()
-    out = fo.unet_3d_3d(sd, x, 1, size, 4)
-    loss = (out - tgt).abs().mean()
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 forward+backward step of the same 1x1x{size}^3 fp32 workload through oracle/flavr_oracle.py "
-                      f"({dt:.1f} s, no optimizer)"}
+    threads = torch.get_num_threads()
+    times, first = [], None
+    for it in range(1 + timed):
+        sd = {k: v.detach().clone().requires_grad_() for k, v in state_dict.items()}
+        t0 = time.perf_counter()
+        out = fo.unet_3d_3d(sd, x.clone(), 1, size, 4)
+        loss = (out - tgt).abs().mean()
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it == 0:
+            first = (out.detach(), float(loss))
+        else:
+            times.append(dt)
+        del sd, out, loss
+    times.sort()
+    med = times[len(times) // 2]
+    rec = {"value": 1.0 / med, "unit": "patches/s", "cores": threads, "physical_cores": physical_cores(),
+           "logical_cpus": os.cpu_count(), "kind": "port",
+           "sample": f"forward+backward of the same 1x1x{size}^3 fp32 workload (same weights, input and target as the GPU "
+                     f"model) through oracle/flavr_oracle.py on {threads} torch threads: 1 warm-up + {timed} timed steps, "
+                     f"median {med:.1f} s (min {times[0]:.1f}, max {times[-1]:.1f}); no optimizer step"}
+    return rec, first
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=128, help="patch edge (128 = BASELINE config)")
     ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref", "cfg4"], default="flavr",
                     help="flavr = configs[1] (headline); seg = configs[2] (SegModel 2x1x128^3, secondary); "
@@ -76,6 +102,7 @@ def main():
                          "(B,2,4,96,96) with the UASR head (configs/brain.yaml)")
     ap.add_argument("--batch", type=int, default=32, help="batch of the flavr_ref workload (brain.yaml: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps of the cpu_baseline leg (after 1 warm-up)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
@@ -196,6 +223,19 @@ def main():
             opt.step()
             return loss
 
+    # CPU leg FIRST (rank 0, N=1, headline workload): the oracle on the host cores with the GPU model's own initial
+    # weights and patch; its warm-up step doubles as the parity check of the HIP forward (north_star: within 1e-3).
+    cpu_rec = parity = None
+    if world == 1 and not args.no_cpu_baseline and args.workload == "flavr":
+        sd0 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cpu_rec, (ref_out, ref_loss) = cpu_baseline(size, sd0, x.cpu(), tgt.cpu(), args.cpu_steps)
+        with torch.no_grad():
+            out0 = model(x.clone())
+            loss0 = float((out0 - tgt).abs().mean())
+        parity = {"fwd_rel": float((out0.cpu() - ref_out).abs().max() / ref_out.abs().max()),
+                  "loss_rel": abs(loss0 - ref_loss) / abs(ref_loss), "loss_hip": loss0, "loss_cpu": ref_loss,
+                  "what": "HIP forward vs the CPU oracle's forward on identical weights / input, before the first step"}
+        del sd0, ref_out, out0
     for _ in range(args.warmup):
         step()
     if dist.is_initialized():
@@ -227,52 +267,56 @@ def main():
                        "parallelism": f"dp{world} (patch-parallel, flat-bucket RCCL all-reduce)"},
             "loss": float(loss.item()),
         }
+        EXEC = {"wino_conv": 16.0 / 36.0, "wino_wgrad": 16.0 / 36.0,      # F(2x2,3x3): 16 of 36 products issued
+                "wino22_conv": 9.0 / 16.0, "wino22_wgrad": 9.0 / 16.0,    # F(2x2,2x2): 9 of 16
+                "gather_gemm": 1.0, "wgrad": 1.0}
+
         def fam(name):
+            """Roofline record of a kernel family.  `achieved` / `frac` price the MFMA work the kernels ISSUE
+            (a fraction <= 1 of the matrix pipe); `algorithmic_*` price the direct-convolution FLOPs the layer
+            needs, which the Winograd kernels reach with 16/36 resp. 9/16 of the products."""
             f = prof.get(name)
             if not f or f["seconds"] <= 0:
                 return None
-            a = f["flops"] / f["seconds"] / 1e12
-            return {"bound": "mfma", "achieved": a, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": a / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": f["launches"] / args.steps,
+            alg = f["flops"] / f["seconds"] / 1e12
+            ex = alg * EXEC[name]
+            return {"bound": "mfma", "achieved": ex, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ex / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "algorithmic_achieved": alg, "algorithmic_frac": alg / FP32_MFMA_PEAK_TFLOPS,
+                    "mfma_products_issued_per_algorithmic": EXEC[name],
+                    "launches_per_step": f["launches"] / args.steps,
                     "avg_launch_ms": f["seconds"] / f["launches"] * 1e3,
                     "ms_per_step": f["seconds"] / args.steps * 1e3,
                     "algorithmic_gflop_per_step": f["flops"] / args.steps / 1e9}
 
-        wc = fam("wino_conv")
-        if wc:
-            # Dominant kernel: wino_conv_big_kernel / wino_conv_kernel (unit-stride 3x3x3 and 1x3x3 conv
-            # forward + input gradient).  `achieved` prices the ALGORITHMIC (direct-convolution) flops of the
-            # launches, as DESIGN.md defines them; the kernel executes 16/36 of those multiplications on the
-            # matrix cores (Winograd F(2x2,3x3) over H,W), so frac can exceed 1 -- `executed_*` is the MFMA work
-            # actually issued against the same peak.
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if args.workload == "flavr" and size == 128 and os.path.exists(tp):
-                traffic = json.load(open(tp))["kernels"].get("wino_conv_big", {}).get("hbm_bytes_per_launch")
-            wc["traffic"] = traffic
-            wc["kernel"] = ("wino_conv_big_kernel + wino_conv_kernel: Winograd F(2x2,3x3)-over-(H,W) fp32 MFMA conv "
-                            "forward / input gradient")
-            wc["executed_tflops"] = wc["achieved"] * 16.0 / 36.0
-            wc["executed_frac"] = wc["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS
-            rec["roofline"] = wc
-        for name, key in (("gather_gemm", "roofline_gather_gemm"), ("wino_wgrad", "roofline_wino_wgrad"),
-                          ("wino22_conv", "roofline_wino22_conv"), ("wino22_wgrad", "roofline_wino22_wgrad"),
-                          ("wgrad", "roofline_wgrad")):
-            f = fam(name)
-            if f:
-                if name.startswith("wino"):  # F(2x2,3x3): 16 of 36 products; F(2x2,2x2): 9 of 16
-                    k = 16.0 / 36.0 if name == "wino_wgrad" else 9.0 / 16.0
-                    f["executed_tflops"] = f["achieved"] * k
-                    f["executed_frac"] = f["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS
-                if not wc and name == "gather_gemm":
-                    f["traffic"] = None
-                    rec["roofline"] = f
-                else:
-                    rec[key] = f
+        names = {"wino_conv": "wino_conv_big_kernel / wino_conv_w32_kernel / wino_conv_kernel / wino_flat_conv_kernel: "
+                              "Winograd F(2x2,3x3)-over-(H,W) fp32 MFMA conv forward / input gradient",
+                 "gather_gemm": "gather_gemm_kernel / halo_conv_kernel: fp32 MFMA implicit-GEMM conv (strided, 1x1x1, "
+                                "transposed phases)"}
+        fams = {n: fam(n) for n in EXEC}
+        dominant = max((n for n in fams if fams[n]), key=lambda n: fams[n]["ms_per_step"], default=None)
+        if dominant:
+            r = fams[dominant]
+            r["kernel"] = names.get(dominant, dominant)
+            # HBM bytes per launch from the committed PMC passes of the same command (tools/pmc_traffic.py; rocprofv3
+            # counters cannot be collected from inside the timed run)
+            for tp in ("r02_pmc_hbm.json", "r01_pmc_traffic.json"):
+                tp = os.path.join(ROOT, "profiles", tp)
+                if args.workload == "flavr" and size == 128 and dominant == "wino_conv" and os.path.exists(tp):
+                    k = json.load(open(tp)).get("kernels", {}).get("wino_conv_big", {})
+                    if k.get("hbm_bytes_per_launch"):
+                        r["traffic"] = k["hbm_bytes_per_launch"]
+                        r["traffic_source"] = "profiles/" + os.path.basename(tp)
+                        break
+            rec["roofline"] = r
+        for n, r in fams.items():
+            if r and n != dominant:
+                rec["roofline_" + n] = r
         if prof:
             rec["mfma_kernel_ms_per_step"] = sum(v["seconds"] for v in prof.values()) / args.steps * 1e3
-        if world == 1 and not args.no_cpu_baseline and args.workload == "flavr":
-            rec["cpu_baseline"] = cpu_baseline(size)
+        if cpu_rec is not None:
+            rec["cpu_baseline"] = cpu_rec
+            rec["parity_vs_cpu"] = parity
         print(json.dumps(rec), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
