@@ -105,29 +105,6 @@ __global__ __launch_bounds__(256) void se_gate_bwd_k_kernel(const double* __rest
   if (sl == 0 && k < C) kconst[(int64_t)n * C + k] = (part[0][kl] + part[1][kl] + part[2][kl] + part[3][kl]) * invS;
 }
 
-// ---------------------------------------------------------------- y = act(x*gate + res)
-__global__ void scale_res_act_fwd_kernel(const float* __restrict__ x, int ldx,
-                                         const float* __restrict__ gate,
-                                         const float* __restrict__ res, int ldr,
-                                         float* __restrict__ y, int ldy, int64_t rows, int64_t S,
-                                         int C, int act, float slope) {
-  const int c4n = C >> 2;
-  const int64_t total = rows * c4n;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    const int64_t row = i / c4n;
-    const int n = (int)(row / S);
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (int64_t)n * C + c);
-    f32x4 v = xv * gv;
-    if (res != nullptr) v += *reinterpret_cast<const f32x4*>(res + row * ldr + c);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
-    *reinterpret_cast<f32x4*>(y + row * ldy + c) = v;
-  }
-}
-
 // Column-reduction skeleton: a block owns `rows_per_block` consecutive rows of
 // ONE sample; thread t owns channel quad (t % c4n) and walks rows t / c4n,
 // + rpp, ...  NQ quantities x 4 channels are reduced over the block in LDS and
@@ -160,162 +137,6 @@ __device__ __forceinline__ void column_reduce(int64_t row_begin, int64_t row_end
     for (int k = 0; k < rpp; ++k) s += red[qe * EW_THREADS + k * c4n + cqq];
     const int qn = qe >> 2, e = qe & 3;
     atomicAdd(out + (int64_t)(cqq * 4 + e) * out_stride + qn, s);
-  }
-}
-
-// dz = dy*act'(y); dres = dz; dx = dz*gate; dgate_acc[n][c] += sum dz*x
-__global__ void scale_res_act_bwd_kernel(const float* __restrict__ dy, int lddy,
-                                         const float* __restrict__ y, int ldy,
-                                         const float* __restrict__ x, int ldx,
-                                         const float* __restrict__ gate, float* __restrict__ dx,
-                                         int lddx, float* __restrict__ dres, int lddr,
-                                         double* __restrict__ dgate_acc, int64_t S, int C,
-                                         int64_t rows_per_block, int act, float slope) {
-  const int n = blockIdx.y;
-  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
-  int64_t s_end = s_begin + rows_per_block;
-  if (s_end > S) s_end = S;
-  const int64_t base = (int64_t)n * S;
-  column_reduce<1>(base + s_begin, base + s_end, C, dgate_acc + (int64_t)n * C, 1,
-                   [&](int64_t row, int c, double(&acc)[1][4]) {
-                     const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
-                     const f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ldy + c);
-                     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
-                     const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (int64_t)n * C + c);
-                     f32x4 dz;
-#pragma unroll
-                     for (int e = 0; e < 4; ++e) dz[e] = dyv[e] * act_grad(yv[e], act, slope);
-                     if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + row * lddr + c) = dz;
-                     *reinterpret_cast<f32x4*>(dx + row * lddx + c) = dz * gv;
-#pragma unroll
-                     for (int e = 0; e < 4; ++e) acc[0][e] += dz[e] * xv[e];
-                   });
-}
-
-__global__ void add_channel_const_kernel(float* __restrict__ x, int ldx, const float* __restrict__ k,
-                                         int64_t rows, int64_t S, int C) {
-  const int c4n = C >> 2;
-  const int64_t total = rows * c4n;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    const int64_t row = i / c4n;
-    const int n = (int)(row / S);
-    f32x4* p = reinterpret_cast<f32x4*>(x + row * ldx + c);
-    *p = *p + *reinterpret_cast<const f32x4*>(k + (int64_t)n * C + c);
-  }
-}
-
-// ---------------------------------------------------------------- InstanceNorm + act
-__global__ void instnorm_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mr,
-                                         int64_t NC, double invS, float eps) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NC;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const double m = stats[i * 2] * invS;
-    double var = stats[i * 2 + 1] * invS - m * m;
-    if (var < 0.0) var = 0.0;
-    mr[i * 2] = (float)m;
-    mr[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-}
-
-__global__ void instnorm_act_fwd_kernel(const float* __restrict__ x, int ldx,
-                                        const float* __restrict__ mr,
-                                        const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, float* __restrict__ y,
-                                        int ldy, int64_t rows, int64_t S, int C, int act,
-                                        float slope) {
-  const int c4n = C >> 2;
-  const int64_t total = rows * c4n;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    const int64_t row = i / c4n;
-    const int n = (int)(row / S);
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
-    const float* m = mr + ((int64_t)n * C + c) * 2;
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xh = (xv[e] - m[2 * e]) * m[2 * e + 1];
-      v[e] = apply_act(xh * gamma[c + e] + beta[c + e], act, slope);
-    }
-    *reinterpret_cast<f32x4*>(y + row * ldy + c) = v;
-  }
-}
-
-// pass 1: red[n][c] = { sum dz, sum dz*xhat },  dz = dy * act'(xhat*gamma+beta)
-__global__ void instnorm_bwd_reduce_kernel(const float* __restrict__ dy, int lddy,
-                                           const float* __restrict__ x, int ldx,
-                                           const float* __restrict__ mr,
-                                           const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, double* __restrict__ red,
-                                           int64_t S, int C, int64_t rows_per_block, int act,
-                                           float slope) {
-  const int n = blockIdx.y;
-  const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
-  int64_t s_end = s_begin + rows_per_block;
-  if (s_end > S) s_end = S;
-  const int64_t base = (int64_t)n * S;
-  column_reduce<2>(base + s_begin, base + s_end, C, red + (int64_t)n * C * 2, 2,
-                   [&](int64_t row, int c, double(&acc)[2][4]) {
-                     const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
-                     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
-                     const float* m = mr + ((int64_t)n * C + c) * 2;
-#pragma unroll
-                     for (int e = 0; e < 4; ++e) {
-                       const float xh = (xv[e] - m[2 * e]) * m[2 * e + 1];
-                       const float z = xh * gamma[c + e] + beta[c + e];
-                       const float dz = dyv[e] * act_grad(z, act, slope);
-                       acc[0][e] += dz;
-                       acc[1][e] += dz * xh;
-                     }
-                   });
-}
-// dgamma[c] = sum_n red[n][c][1]; dbeta[c] = sum_n red[n][c][0]
-__global__ void instnorm_bwd_params_kernel(const double* __restrict__ red, float* __restrict__ dgamma,
-                                           float* __restrict__ dbeta, int N, int C) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-    double a = 0.0, b = 0.0;
-    for (int n = 0; n < N; ++n) {
-      b += red[((int64_t)n * C + c) * 2];
-      a += red[((int64_t)n * C + c) * 2 + 1];
-    }
-    dgamma[c] = (float)a;
-    dbeta[c] = (float)b;
-  }
-}
-// pass 2: dx = rstd*gamma*(dz - m1 - xhat*m2)
-__global__ void instnorm_bwd_apply_kernel(const float* __restrict__ dy, int lddy,
-                                          const float* __restrict__ x, int ldx,
-                                          const float* __restrict__ mr,
-                                          const float* __restrict__ gamma,
-                                          const float* __restrict__ beta,
-                                          const double* __restrict__ red, float* __restrict__ dx,
-                                          int lddx, int64_t rows, int64_t S, int C, int act,
-                                          float slope) {
-  const int c4n = C >> 2;
-  const int64_t total = rows * c4n;
-  const double invS = 1.0 / (double)S;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    const int64_t row = i / c4n;
-    const int n = (int)(row / S);
-    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c);
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
-    const float* m = mr + ((int64_t)n * C + c) * 2;
-    const double* rd = red + ((int64_t)n * C + c) * 2;
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xh = (xv[e] - m[2 * e]) * m[2 * e + 1];
-      const float z = xh * gamma[c + e] + beta[c + e];
-      const float dz = dyv[e] * act_grad(z, act, slope);
-      const float m1 = (float)(rd[2 * e] * invS), m2 = (float)(rd[2 * e + 1] * invS);
-      o[e] = m[2 * e + 1] * gamma[c + e] * (dz - m1 - xh * m2);
-    }
-    *reinterpret_cast<f32x4*>(dx + row * lddx + c) = o;
   }
 }
 
@@ -773,39 +594,6 @@ extern "C" int rehr_se_gate_fwd_f32(const double* stats, const float* w, const f
   return REHR_OK;
 }
 
-extern "C" int rehr_scale_res_act_fwd_f32(const float* x, int32_t ldx, const float* gate,
-                                          const float* res, int32_t ldr, float* y, int32_t ldy,
-                                          int32_t N, int64_t S, int32_t C, int32_t act, float slope,
-                                          void* stream) {
-  if (!x || !gate || !y || N < 1 || S < 1 || C < 4 || C % 4 || ldx % 4 || ldy % 4 || (res && ldr % 4))
-    return REHR_EINVAL;
-  if (!aligned16(x) || !aligned16(y) || !aligned16(gate) || (res && !aligned16(res))) return REHR_EINVAL;
-  const int64_t rows = (int64_t)N * S;
-  hipLaunchKernelGGL(scale_res_act_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
-                     x, ldx, gate, res, ldr, y, ldy, rows, S, C, act, slope);
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
-
-extern "C" int rehr_scale_res_act_bwd_f32(const float* dy, int32_t lddy, const float* y, int32_t ldy,
-                                          const float* x, int32_t ldx, const float* gate, float* dx,
-                                          int32_t lddx, float* dres, int32_t lddr, double* dgate_acc,
-                                          int32_t N, int64_t S, int32_t C, int32_t act, float slope,
-                                          void* stream) {
-  if (!dy || !y || !x || !gate || !dx || !dgate_acc) return REHR_EINVAL;
-  if (N < 1 || N > 65535 || S < 1 || C < 4 || C % 4 || C > 1024) return REHR_EINVAL;
-  if (lddy % 4 || ldy % 4 || ldx % 4 || lddx % 4 || (dres && lddr % 4)) return REHR_EINVAL;
-  if (!aligned16(dy) || !aligned16(y) || !aligned16(x) || !aligned16(dx) || !aligned16(gate) ||
-      (dres && !aligned16(dres)))
-    return REHR_EINVAL;
-  const int64_t rpb = rows_per_block_for(S, C, N);
-  const int blocks = (int)((S + rpb - 1) / rpb);
-  hipLaunchKernelGGL(scale_res_act_bwd_kernel, dim3(blocks, N), dim3(EW_THREADS), 0, ST, dy, lddy, y,
-                     ldy, x, ldx, gate, dx, lddx, dres, lddr, dgate_acc, S, C, rpb, act, slope);
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
-
 extern "C" int rehr_se_gate_bwd_f32(const double* dgate_acc, const float* gate, const float* mean,
                                     const float* w, float* dw, float* db, float* kconst, int32_t N,
                                     int32_t C, int64_t S, void* stream) {
@@ -815,56 +603,6 @@ extern "C" int rehr_se_gate_bwd_f32(const double* dgate_acc, const float* gate, 
                      dgate_acc, gate, mean, dw, db, N, C);
   hipLaunchKernelGGL(se_gate_bwd_k_kernel, dim3((C + 63) / 64, N), dim3(256), 0, ST, dgate_acc, gate, w, kconst, N, C,
                      (float)(1.0 / (double)S));
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
-
-extern "C" int rehr_add_channel_const_f32(float* x, int32_t ldx, const float* k, int32_t N, int64_t S,
-                                          int32_t C, void* stream) {
-  if (!x || !k || N < 1 || S < 1 || C < 4 || C % 4 || ldx % 4 || !aligned16(x) || !aligned16(k))
-    return REHR_EINVAL;
-  const int64_t rows = (int64_t)N * S;
-  hipLaunchKernelGGL(add_channel_const_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
-                     x, ldx, k, rows, S, C);
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
-
-extern "C" int rehr_instnorm_act_fwd_f32(const float* x, int32_t ldx, const double* stats,
-                                         const float* gamma, const float* beta, float* y, int32_t ldy,
-                                         float* mean_rstd, int32_t N, int64_t S, int32_t C, float eps,
-                                         int32_t act, float slope, void* stream) {
-  if (!x || !stats || !gamma || !beta || !y || !mean_rstd) return REHR_EINVAL;
-  if (N < 1 || S < 1 || C < 4 || C % 4 || ldx % 4 || ldy % 4 || !aligned16(x) || !aligned16(y))
-    return REHR_EINVAL;
-  const int64_t NC = (int64_t)N * C;
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ew_blocks(NC)), dim3(EW_THREADS), 0, ST, stats,
-                     mean_rstd, NC, 1.0 / (double)S, eps);
-  const int64_t rows = (int64_t)N * S;
-  hipLaunchKernelGGL(instnorm_act_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
-                     x, ldx, mean_rstd, gamma, beta, y, ldy, rows, S, C, act, slope);
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
-
-extern "C" int rehr_instnorm_act_bwd_f32(const float* dy, int32_t lddy, const float* x, int32_t ldx,
-                                         const float* mean_rstd, const float* gamma, const float* beta,
-                                         float* dx, int32_t lddx, float* dgamma, float* dbeta,
-                                         double* red, int32_t N, int64_t S, int32_t C, int32_t act,
-                                         float slope, void* stream) {
-  if (!dy || !x || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red) return REHR_EINVAL;
-  if (N < 1 || N > 65535 || S < 1 || C < 4 || C % 4 || C > 1024) return REHR_EINVAL;
-  if (lddy % 4 || ldx % 4 || lddx % 4 || !aligned16(dy) || !aligned16(x) || !aligned16(dx))
-    return REHR_EINVAL;
-  const int64_t rpb = rows_per_block_for(S, C, N);
-  const int blocks = (int)((S + rpb - 1) / rpb);
-  hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(blocks, N), dim3(EW_THREADS), 0, ST, dy, lddy, x,
-                     ldx, mean_rstd, gamma, beta, red, S, C, rpb, act, slope);
-  hipLaunchKernelGGL(instnorm_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, red, dgamma,
-                     dbeta, N, C);
-  const int64_t rows = (int64_t)N * S;
-  hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0, ST,
-                     dy, lddy, x, ldx, mean_rstd, gamma, beta, red, dx, lddx, rows, S, C, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

@@ -110,12 +110,12 @@ def test_cfg2_flavr_128cube_against_cpu_reference_path():
     for dt in (torch.float32, torch.float64):
         with heartbeat("cfg2"):
             t0 = time.time()
-            osd = {k: v.to(dt).requires_grad_() for k, v in sd.items()}
+            osd = {k: v.detach().clone().to(dt).requires_grad_() for k, v in sd.items()}
             xr = x.to(dt).clone()
             r = fo.unet_3d_3d(osd, xr, 1, 128, 4)
             rl = (r - tgt.to(dt)).abs().mean()
             rl.backward()
-            runs[dt] = (r.detach(), float(rl), {k: v.grad for k, v in osd.items()}, xr)
+            runs[dt] = (r.detach(), float(rl.detach()), {k: v.grad for k, v in osd.items()}, xr)
             print(f"[cfg2] oracle {dt} step: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
     r32, l32, g32, x32 = runs[torch.float32]
     fwd = float((out.detach().cpu() - r32).abs().max() / r32.abs().max())
@@ -155,11 +155,11 @@ def test_cfg3_segmodel_128cube_against_cpu_reference_path():
     for dt in (torch.float32, torch.float64):
         with heartbeat("cfg3"):
             t0 = time.time()
-            osd = {k: v.to(dt).requires_grad_() for k, v in sd.items() if k in so.segmodel_shapes(so.ISO_PLAN)}
+            osd = {k: v.detach().clone().to(dt).requires_grad_() for k, v in sd.items() if k in so.segmodel_shapes(so.ISO_PLAN)}
             r_out, r_up = so.seg_model(osd, x.to(dt), so.ISO_PLAN)
             rl = ao.dc_and_weighted_ce(r_out, lab_lr.to(dt)) + ao.dc_and_weighted_ce(r_up, lab_hr.to(dt))
             rl.backward()
-            runs[dt] = (r_out.detach(), r_up.detach(), float(rl), {k: v.grad for k, v in osd.items()})
+            runs[dt] = (r_out.detach(), r_up.detach(), float(rl.detach()), {k: v.grad for k, v in osd.items()})
             del r_out, r_up, rl, osd
             print(f"[cfg3] oracle {dt} step: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
     r_out, r_up, l32, g32 = runs[torch.float32]
