@@ -99,7 +99,11 @@ typedef struct {
    * (same fp32 results up to the transform's rounding, ~1e-6 relative).          */
   float* wino_ws;
   int64_t wino_ws_bytes;
+  int32_t flags;                   /* REHR_GG_* bits (bf16 entry points only; the fp32 ones ignore it) */
 } rehr_gather_gemm_desc;
+
+/* bf16 entry points: store y as fp32 instead of bf16 (logits, features handed to fp32 losses) */
+#define REHR_GG_Y_F32 1
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
@@ -108,6 +112,19 @@ int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);
  * only in lattice, taps and destination offset, in a single grid.                   */
 int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, int32_t count,
                                void* stream);
+/* Mixed-precision variants (BASELINE.json configs[4]: bf16 conv inputs / weights, fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16, fp32 bias / fp64 statistics formed from the fp32 accumulators): the SAME descriptor
+ * with x1, x2, wp and y pointing at bf16 elements (ld* and channel counts stay in ELEMENTS; rows must be
+ * 16-byte aligned: ldx % 8 == 0; c1 % 32 == 0 when x2 is used), y fp32 with REHR_GG_Y_F32; wino_ws is
+ * ignored (the bf16 pipe is 16x the fp32 one: the direct contraction is operand-bandwidth bound already).
+ * rehr_pack_weights_bf16: the torch parameter layout in[a][b][t] (transpose_ab: in[b][a][t]) fp32 ->
+ * out[t][Apad][B] bf16 -- master weights stay fp32.
+ * Replaces the same torch.nn.Conv3d / ConvTranspose3d call sites under bf16 autocast.                */
+int rehr_gather_gemm_bf16(const rehr_gather_gemm_desc* d, void* stream);
+int rehr_gather_gemm_multi_bf16(const rehr_gather_gemm_desc* descs, int32_t count, void* stream);
+int rehr_pack_weights_bf16(const float* in, void* out, int32_t A, int32_t Apad, int32_t B, int32_t T,
+                           int32_t transpose_ab, void* stream);
+
 /* Split-K combine: y[row][c] = act(bias[c] + sum_s slabs[s*slab_stride + row*C + c]).
  * A contraction with few lattice tiles and very many taps (feature_fuse:
  * models/FLAVR/FLAVR_arch.py:145, 16384 voxels x 1152 taps) is launched as S

@@ -101,8 +101,9 @@ def _chk_dev(*ts, f64=()):
             continue
         if not t.is_cuda:
             raise L.RehrsegHipError("librehrseg_hip.so needs device tensors (no CPU fallback)")
-        if t.dtype != torch.float32:
-            raise L.RehrsegHipError(f"unsupported dtype {t.dtype} (the kernels read float32)")
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise L.RehrsegHipError(f"unsupported dtype {t.dtype} (the kernels read float32, the mixed-precision "
+                                    "variants bfloat16)")
     for t in f64:
         if t is None:
             continue
@@ -110,17 +111,26 @@ def _chk_dev(*ts, f64=()):
             raise L.RehrsegHipError("statistics buffers are float64 device tensors")
 
 
-def new_act(N, Cc, D, H, W, like, zero=False):
-    t = torch.empty((N, Cc, D, H, W), dtype=torch.float32, device=like.device, memory_format=torch.channels_last_3d)
+def new_act(N, Cc, D, H, W, like, zero=False, dtype=None):
+    """NDHWC activation in `like`'s dtype (fp32, or bf16 on the mixed-precision path) unless `dtype` says otherwise."""
+    dt = dtype if dtype is not None else (like.dtype if like.dtype == torch.bfloat16 else torch.float32)
+    t = torch.empty((N, Cc, D, H, W), dtype=dt, device=like.device, memory_format=torch.channels_last_3d)
     return t.zero_() if zero else t
 
 
-def pack_weights(w, A, Apad, B, T, transpose):
+def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
+    """fp32 master weights in the torch parameter layout -> kernel panel [T][Apad][B] in `dtype` (fp32 / bf16)."""
     _chk_dev(w)
     w = w.contiguous()
-    out = torch.empty((T, Apad, B), dtype=torch.float32, device=w.device)
-    L.check(L.load().rehr_pack_weights_f32(_ptr(w), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
-            "rehr_pack_weights_f32")
+    if w.dtype != torch.float32:
+        raise L.RehrsegHipError("master weights are float32")
+    out = torch.empty((T, Apad, B), dtype=dtype, device=w.device)
+    if dtype == torch.bfloat16:
+        L.check(L.load().rehr_pack_weights_bf16(_ptr(w), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
+                "rehr_pack_weights_bf16")
+    else:
+        L.check(L.load().rehr_pack_weights_f32(_ptr(w), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
+                "rehr_pack_weights_f32")
     return out
 
 
@@ -157,8 +167,17 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d.stats, d.stats_mode = _ptr(stats), stats_mode
     d.tile_d, d.tile_h, d.tile_w = tile
     d.wino_ws, d.wino_ws_bytes = None, 0
+    d.flags = 0
     keep = None
-    if USE_WINOGRAD and tile[0] >= 0:
+    if x1.dtype == torch.bfloat16:
+        if wp.dtype != torch.bfloat16 or (x2 is not None and x2.dtype != torch.bfloat16):
+            raise L.RehrsegHipError("mixed-precision gather-GEMM: x1, x2 and the packed weights must all be bfloat16")
+        if bias is not None and bias.dtype != torch.float32:
+            raise L.RehrsegHipError("bias stays float32")
+        d.flags = L.GG_Y_F32 if y.dtype == torch.float32 else 0
+    elif wp.dtype != torch.float32 or y.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
+        raise L.RehrsegHipError("fp32 gather-GEMM: every operand must be float32")
+    elif USE_WINOGRAD and tile[0] >= 0:
         nbytes = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
         if nbytes > 0:
             keep = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
@@ -180,6 +199,10 @@ def _gg_family(d):
 def gather_gemm(*args):
     d = L.GatherGemmDesc()
     flops = _gg_desc(d, *args)
+    if args[0].dtype == torch.bfloat16:
+        with _timed("gather_gemm_bf16", flops):
+            L.check(L.load().rehr_gather_gemm_bf16(C.byref(d), _stream()), "rehr_gather_gemm_bf16")
+        return
     with _timed(_gg_family(d), flops):
         L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
 
@@ -193,6 +216,10 @@ def gather_gemm_multi(calls):
     for i, a in enumerate(calls):
         flops += _gg_desc(arr[i], *a)
         keeps.append(_gg_desc.last_keep)
+    if calls[0][0].dtype == torch.bfloat16:
+        with _timed("gather_gemm_bf16", flops):
+            L.check(L.load().rehr_gather_gemm_multi_bf16(arr, len(calls), _stream()), "rehr_gather_gemm_multi_bf16")
+        return
     with _timed(_gg_family(arr[0]) if all(arr[i].wino_ws for i in range(len(calls))) else "gather_gemm", flops):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 

@@ -17,6 +17,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rehrseg_hip.h")
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 ABI_VERSION = 2
 WGRAD_DIRECT = 1  # rehr_wgrad_desc.flags
+GG_Y_F32 = 1      # rehr_gather_gemm_desc.flags
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p
@@ -46,6 +47,7 @@ class GatherGemmDesc(C.Structure):
         ("stats", _vp), ("stats_mode", _i32),
         ("tile_d", _i32), ("tile_h", _i32), ("tile_w", _i32),
         ("wino_ws", _vp), ("wino_ws_bytes", _i64),
+        ("flags", _i32),
     ]
 
 
@@ -83,6 +85,9 @@ PROTOTYPES = {
     "rehr_gather_gemm_wino_bytes": (_i64, [_P_GG]),
     "rehr_gather_gemm_f32": (C.c_int, [_P_GG, _vp]),
     "rehr_gather_gemm_multi_f32": (C.c_int, [_P_GG, _i32, _vp]),
+    "rehr_gather_gemm_bf16": (C.c_int, [_P_GG, _vp]),
+    "rehr_gather_gemm_multi_bf16": (C.c_int, [_P_GG, _i32, _vp]),
+    "rehr_pack_weights_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "rehr_sum_slabs_bias_act_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "rehr_sum_slabs_stats_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp]),
     "rehr_wgrad_workspace_bytes": (_i64, [_P_WG]),

@@ -45,10 +45,10 @@ def set_backend(b):
 
 # ----------------------------------------------------------------------------- layout
 def to_cl(x: torch.Tensor) -> torch.Tensor:
-    """Logical (N,C,D,H,W) tensor whose memory is NDHWC-dense, fp32."""
+    """Logical (N,C,D,H,W) tensor whose memory is NDHWC-dense; fp32, or bf16 on the mixed-precision path."""
     if x.dim() != 5:
         raise ValueError(f"expected a 5-D (N,C,D,H,W) tensor, got {tuple(x.shape)}")
-    if x.dtype not in (torch.float32, torch.float64):  # float64 only ever reaches the CPU emulator in tests
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float64):  # float64 only reaches the CPU emulator in tests
         x = x.float()
     if x.permute(0, 2, 3, 4, 1).is_contiguous():
         return x
@@ -142,15 +142,17 @@ def _out_dims(in_dims, w_shape, cfg: ConvCfg):
     return tuple(conv_out_dim(i, k, s, p) for i, k, s, p in zip(in_dims, K, cfg.stride, cfg.pad))
 
 
-def _pack(w, dest_dim):
-    """wp[tap][dest rows (padded)][other dim]; dest_dim = which weight dim feeds the output channels."""
+def _pack(w, dest_dim, dtype=torch.float32):
+    """wp[tap][dest rows (padded)][other dim] in `dtype` (the activations' dtype: fp32, or bf16 on the mixed-precision
+    path -- the master weights `w` stay fp32); dest_dim = which weight dim feeds the output channels."""
     be = get_backend()
     T = w.shape[2] * w.shape[3] * w.shape[4]
+    kw = {"dtype": torch.bfloat16} if dtype == torch.bfloat16 else {}
     if dest_dim == 0:
         A, B = w.shape[0], w.shape[1]
-        return be.pack_weights(w, A, pad_rows(A), B, T, False), pad_rows(A)
+        return be.pack_weights(w, A, pad_rows(A), B, T, False, **kw), pad_rows(A)
     A, B = w.shape[1], w.shape[0]
-    return be.pack_weights(w, A, pad_rows(A), B, T, True), pad_rows(A)
+    return be.pack_weights(w, A, pad_rows(A), B, T, True, **kw), pad_rows(A)
 
 
 def _phased_gather(src1, src2, c1, Csrc, wp, Npad, dst, Cdst, K, stride, pad, bias, act, slope, stats, stats_mode):
@@ -251,16 +253,17 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
         if empty and bias is not None:
             raise NotImplementedError("ConvTranspose3d with unreachable output phases and a bias")
         y = be.new_act(N, Cout, *out_dims, like=x1, zero=empty)
-        wp, Npad = _pack(w, 1)
+        wp, Npad = _pack(w, 1, x1.dtype)
         _phased_gather(x1, x2, c1, Cin, wp, Npad, y, Cout, K, cfg.stride, cfg.pad, bias, act, slope, stats,
                        stats_mode)
         return y, stats
-    wp, Npad = _pack(w, 0)
+    wp, Npad = _pack(w, 0, x1.dtype)
     taps = [full_taps(k) for k in K]
     # Few lattice tiles but a long K (feature_fuse: 128 tiles x 1152 taps; nnU-Net stages at <= 8^3 voxels:
     # 40 tiles x 27 taps x 320 channels): split the taps over S partial launches in one grid and combine the
     # slabs in a fixed order (the combine carries bias, activation and the statistics epilogue).
-    parts = _tap_split(out_dims, N, Npad, taps, Cin) if cfg.stride == (1, 1, 1) or K[0] >= 8 else None
+    bf16 = x1.dtype == torch.bfloat16   # (the split-K combine kernels are fp32; bf16 layers run unsplit)
+    parts = _tap_split(out_dims, N, Npad, taps, Cin) if (cfg.stride == (1, 1, 1) or K[0] >= 8) and not bf16 else None
     if parts is not None and Cout % 4 == 0:
         S = len(parts)
         slabs = be.new_act(S * N, Cout, *out_dims, like=x1)
@@ -292,7 +295,7 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
         if cfg.transposed:
             # dX of ConvTranspose3d = strided Conv3d of dY with w[ci][co] (dest rows = dim 0)
             wpart = w if (lo == 0 and cnt == w.shape[0]) else w[lo:lo + cnt].contiguous()
-            wp, Npad = _pack(wpart, 0)
+            wp, Npad = _pack(wpart, 0, dz.dtype)
             dx = be.new_act(N, cnt, *in_dims, like=dz)
             taps = [full_taps(k) for k in K]
             be.gather_gemm(dz, None, Cz, _spatial(dz), Cz, in_dims, cfg.stride, tuple(-p for p in cfg.pad), taps,
@@ -300,8 +303,8 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
                            0, choose_tile(tuple(in_dims)))
         else:
             wpart = w if (lo == 0 and cnt == w.shape[1]) else w[:, lo:lo + cnt].contiguous()
-            wp, Npad = _pack(wpart, 1)
-            if cfg.stride == (1, 1, 1) and cnt % 4 == 0:
+            wp, Npad = _pack(wpart, 1, dz.dtype)
+            if cfg.stride == (1, 1, 1) and cnt % 4 == 0 and dz.dtype != torch.bfloat16:
                 # low-resolution stages: split the taps like the forward does (one phase, no epilogue)
                 taps = [phase_taps(K[a], 1, cfg.pad[a], 0) for a in range(3)]
                 parts = _tap_split(in_dims, N, Npad, taps, Cz) if all(t is not None for t in taps) else None

@@ -1,0 +1,89 @@
+"""Mixed-precision kernels (BASELINE.json configs[4]: bf16 operands, fp32 accumulate) against torch.nn.functional
+in fp64 evaluated on the SAME bf16-rounded inputs and weights.  Tolerance: what is left is the fp32 accumulation
+order and the final rounding of the output to bf16 (2^-9 relative per element) -> 1e-2 of the tensor's max for
+bf16 outputs, 1e-4 for fp32 outputs / statistics / weight gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rehrseg_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def act(shape, gen, dtype=BF):
+    return torch.randn(shape, generator=gen).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last_3d)
+
+
+def relmax(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+CASES = [  # (N, Cin, Cout, D, H, W, kernel, stride, pad)
+    (2, 64, 64, 6, 20, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # K step 64, 64-wide N tile
+    (1, 128, 128, 4, 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # 128x128 tile
+    (2, 32, 32, 5, 18, 22, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # K step 32, 32-wide N tile
+    (1, 32, 64, 8, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # strided stage entry
+    (1, 64, 128, 6, 16, 16, (3, 3, 3), (1, 2, 2), (1, 1, 1)),
+    (1, 320, 320, 4, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # 5 chunks of 64
+    (1, 48, 96, 4, 10, 12, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # partly empty chunk, padded N
+    (2, 64, 64, 4, 12, 12, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # pointwise
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_forward_and_input_gradient_bf16(case):
+    N, Cin, Cout, D, H, W, K, s, p = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = act((N, Cin, D, H, W), g)
+    w = (torch.randn((Cout, Cin) + K, generator=g) / (Cin * K[0] * K[1] * K[2]) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    cfg = ops.ConvCfg(s, p)
+    y, stats = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.1, 2)
+    assert y.dtype == BF and y.shape[1] == Cout
+    wq = w.to(BF).double()
+    ref = F.leaky_relu(F.conv3d(x.double(), wq, b.double(), s, p), 0.1)
+    assert relmax(y, ref) < 1e-2
+    # statistics come from the fp32 accumulators (before the bf16 rounding of y)
+    assert relmax(stats[..., 0], ref.sum((2, 3, 4))) < 2e-3 and relmax(stats[..., 1], (ref ** 2).sum((2, 3, 4))) < 1e-3
+    dz = act(tuple(ref.shape), g)
+    dx, _ = ops.conv_dgrad(dz, w, (D, H, W), Cin, 0, cfg)
+    assert dx.dtype == BF
+    xr = x.double().requires_grad_()
+    F.conv3d(xr, wq, None, s, p).backward(dz.double())
+    assert relmax(dx, xr.grad) < 1e-2
+
+
+def test_virtual_concat_and_fp32_output_bf16():
+    g = torch.Generator().manual_seed(7)
+    x1, x2 = act((1, 64, 4, 12, 12), g), act((1, 32, 4, 12, 12), g)
+    w = (torch.randn(64, 96, 3, 3, 3, generator=g) / (96 * 27) ** 0.5).to(DEV)
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1))
+    y, _ = ops.conv_forward(x1, x2, w, None, cfg, ops.ACT_NONE, 0.0, 0)
+    ref = F.conv3d(torch.cat([x1, x2], 1).double(), w.to(BF).double(), None, 1, 1)
+    assert relmax(y, ref) < 1e-2
+    dz = act(tuple(ref.shape), g)
+    d1, d2 = ops.conv_dgrad(dz, w, (4, 12, 12), 64, 32, cfg)
+    xr = torch.cat([x1, x2], 1).double().requires_grad_()
+    F.conv3d(xr, w.to(BF).double(), None, 1, 1).backward(dz.double())
+    assert relmax(d1, xr.grad[:, :64]) < 1e-2 and relmax(d2, xr.grad[:, 64:]) < 1e-2
+
+
+@pytest.mark.parametrize("K,s,p", [((2, 2, 2), (2, 2, 2), (0, 0, 0)), ((1, 2, 2), (1, 2, 2), (0, 0, 0)),
+                                   ((3, 4, 4), (1, 2, 2), (1, 1, 1))])
+def test_conv_transpose3d_bf16(K, s, p):
+    g = torch.Generator().manual_seed(11 + K[1])
+    x = act((1, 128, 4, 8, 8), g)
+    w = (torch.randn((128, 64) + K, generator=g) / (128 * K[0]) ** 0.5).to(DEV)
+    b = torch.randn(64, generator=g).to(DEV)
+    cfg = ops.ConvCfg(s, p, transposed=True)
+    y, _ = ops.conv_forward(x, None, w, b, cfg, ops.ACT_NONE, 0.0, 0)
+    ref = F.conv_transpose3d(x.double(), w.to(BF).double(), b.double(), s, p)
+    assert tuple(y.shape) == tuple(ref.shape) and relmax(y, ref) < 1e-2
+    dz = act(tuple(ref.shape), g)
+    dx, _ = ops.conv_dgrad(dz, w, tuple(x.shape[2:]), 128, 0, cfg)
+    xr = x.double().requires_grad_()
+    F.conv_transpose3d(xr, w.to(BF).double(), None, s, p).backward(dz.double())
+    assert relmax(dx, xr.grad) < 1e-2
