@@ -178,6 +178,11 @@ typedef struct {
  * variables and keeps no mutable state between calls. */
 #define REHR_WGRAD_DIRECT 1
 
+/* Mixed-precision weight gradient: l and g point at bf16 elements (ld* in elements, % 8 == 0; Ca, Cg % 8 == 0),
+ * fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 slabs and fp32 dst (the master-weight gradient).  dbias must
+ * be NULL (the bias gradient is a column sum of dY: rehr_channel_sum).  Own workspace query.                  */
+int64_t rehr_wgrad_bf16_workspace_bytes(const rehr_wgrad_desc* d);
+int rehr_wgrad_bf16(const rehr_wgrad_desc* d, void* stream);
 int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* d);
 /* 1 when rehr_wgrad_f32 will take the Winograd path for this descriptor (unit stride,
  * taps {-1,0,+1} over H and W, >= 64 channels on both sides): the products are formed
@@ -390,6 +395,30 @@ int rehr_nchw_to_nhwc_f32(const float* x, float* y, int32_t N, int32_t C,
                           int64_t S, void* stream);
 int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_t C,
                           int64_t S, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Mixed-precision (*_bf16) variants of the HBM-bound fused-block kernels: the SAME arguments as the *_f32 entry
+ * points above with every ACTIVATION pointer (x, y, res, dy, dx, dres) addressing bf16 elements (ld* in elements,
+ * % 8 == 0, C % 8 == 0); gates, gamma / beta, mean_rstd stay fp32, statistics and reduction buffers fp64, the
+ * arithmetic is fp32 in registers.  BASELINE.json configs[4] (bf16 autocast of the same torch.nn call sites).
+ * ------------------------------------------------------------------------- */
+int rehr_scale_res_act_fwd_bf16(const void* x, int32_t ldx, const float* gate, const void* res, int32_t ldr, void* y,
+                                int32_t ldy, int32_t N, int64_t S, int32_t C, int32_t act, float slope, void* stream);
+int rehr_scale_res_act_bwd_bf16(const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x, int32_t ldx,
+                                const float* gate, void* dx, int32_t lddx, void* dres, int32_t lddr,
+                                double* dgate_acc, int32_t N, int64_t S, int32_t C, int32_t act, float slope,
+                                void* stream);
+int rehr_add_channel_const_bf16(void* x, int32_t ldx, const float* k, int32_t N, int64_t S, int32_t C, void* stream);
+int rehr_instnorm_act_fwd_bf16(const void* x, int32_t ldx, const double* stats, const float* gamma, const float* beta,
+                               void* y, int32_t ldy, float* mean_rstd, int32_t N, int64_t S, int32_t C, float eps,
+                               int32_t act, float slope, void* stream);
+int rehr_instnorm_act_bwd_bf16(const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* mean_rstd,
+                               const float* gamma, const float* beta, void* dx, int32_t lddx, float* dgamma,
+                               float* dbeta, double* red, int32_t N, int64_t S, int32_t C, int32_t act, float slope,
+                               void* stream);
+int rehr_channel_sum_bf16(const void* x, int32_t ldx, int64_t rows, int32_t C, float* out, int32_t accumulate,
+                          double* scratch, void* stream);
+int rehr_act_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, int32_t act, float slope, void* stream);
 
 /* ABI version, bumped on any signature change. */
 int rehr_abi_version(void);

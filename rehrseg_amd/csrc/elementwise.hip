@@ -460,30 +460,7 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
     reinterpret_cast<f32x4*>(y)[i] = v;
   }
 }
-__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                               float* __restrict__ dx, int64_t n4, int act, float slope) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-    const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = g[e] * act_grad(v[e], act, slope);
-    reinterpret_cast<f32x4*>(dx)[i] = o;
-  }
-}
 
-__global__ void channel_sum_kernel(const float* __restrict__ x, int ldx, int64_t rows, int C,
-                                   int64_t rows_per_block, double* __restrict__ scratch) {
-  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
-  int64_t r_end = r_begin + rows_per_block;
-  if (r_end > rows) r_end = rows;
-  column_reduce<1>(r_begin, r_end, C, scratch, 1, [&](int64_t row, int c, double(&acc)[1][4]) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[0][e] += v[e];
-  });
-}
 // column sums of dy * act'(y): the bias gradient behind a fused activation without materialising dz
 __global__ void channel_sum_actgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
                                            int64_t rows, int C, int64_t rows_per_block, int act, float slope,
@@ -716,31 +693,6 @@ extern "C" int rehr_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
-extern "C" int rehr_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int32_t act,
-                                float slope, void* stream) {
-  if (!dy || !y || !dx || n < 4 || n % 4 || !aligned16(dy) || !aligned16(y) || !aligned16(dx))
-    return REHR_EINVAL;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, dy, y, dx, n / 4,
-                     act, slope);
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
-
-extern "C" int rehr_channel_sum_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out,
-                                    int32_t accumulate, double* scratch, void* stream) {
-  if (!x || !out || !scratch || rows < 1 || C < 4 || C % 4 || C > 1024 || ldx % 4 || !aligned16(x))
-    return REHR_EINVAL;
-  if (hipMemsetAsync(scratch, 0, sizeof(double) * C, ST) != hipSuccess) return REHR_EHIP;
-  const int64_t rpb = rows_per_block_for(rows, C, 1);
-  const int blocks = (int)((rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST, x, ldx, rows, C, rpb,
-                     scratch);
-  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, scratch, out, C,
-                     accumulate);
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
-
 extern "C" int rehr_channel_sum_actgrad_f32(const float* dy, const float* y, int32_t ld, int64_t rows, int32_t C,
                                             int32_t act, float slope, float* out, double* scratch, void* stream) {
   if (!dy || !y || !out || !scratch || rows < 1 || C < 4 || C % 4 || C > 1024 || ld % 4 || !aligned16(dy) ||

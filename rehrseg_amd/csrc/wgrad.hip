@@ -279,11 +279,226 @@ __global__ void wgrad_reduce_kernel(const WGParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Mixed precision: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 slabs / result.
+// The MFMA k index is the voxel and a lane's fragment is 8 CONSECUTIVE voxels of its channel, while both
+// operands arrive voxel-major ([voxel][channel]): the LDS image keeps that layout (16-byte coalesced stores)
+// and the fragments are read with gfx950's transposing ds_read_b64_tr_b16 -- a 16-lane group fetches a block of
+// 4 voxels x 16 channels and every lane receives its channel's 4 voxels; two reads make the 8-voxel fragment.
+// Row stride = B*2 bytes (+ 64 for B > 32): the 4 voxel rows of a 32-lane half fall into disjoint bank ranges.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int B, int WGA, int WGG, int BKV>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16_kernel(const WGParams p) {
+  constexpr int WTA = B / WGA, WTG = B / WGG;
+  constexpr int FA = WTA / 32, FG = WTG / 32;
+  constexpr int ROW = B * 2 + (B == 32 ? 0 : 64);              // bytes per voxel row of an LDS image
+  constexpr int TPR = B / 8, RPP = NTHREADS / TPR, PASS = BKV / RPP;
+  constexpr int WGK = 4 / (WGA * WGG);
+  constexpr int KSTEPS = (BKV / 16) / WGK;
+  static_assert(WGA * WGG * WGK == 4 && PASS >= 1 && KSTEPS >= 1, "tile shape");
+  const rehr_wgrad_desc& d = p.d;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char* Ls = smem_b;                       // [2][BKV][ROW]
+  unsigned char* Gs = smem_b + 2 * BKV * ROW;       // [2][BKV][ROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WGA * WGG);
+  const int wa = (wave % (WGA * WGG)) / WGG, wg = wave % WGG;
+
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = b % p.c_tiles; b /= p.c_tiles;
+  const int at = b % p.a_tiles; b /= p.a_tiles;
+  const int tap = b;
+  const int jw = tap % d.tw.count;
+  const int jh = (tap / d.tw.count) % d.th.count;
+  const int jd = tap / (d.tw.count * d.th.count);
+  const int dd = d.bd + d.td.off0 + d.td.offs * jd, dh = d.bh + d.th.off0 + d.th.offs * jh,
+            dw = d.bw + d.tw.off0 + d.tw.offs * jw;
+  const int a0 = at * B, c0 = ct * B;
+  const int split = blockIdx.y;
+  const int64_t v_begin = (int64_t)split * p.kv_per_split;
+  int64_t v_end = v_begin + p.kv_per_split;
+  if (v_end > p.kv_total) v_end = p.kv_total;
+  const uint32_t lhw = (uint32_t)d.Lh * d.Lw;
+  const uint32_t lvox = (uint32_t)d.Ld * lhw;
+
+  f32x16 acc[FA][FG];
+#pragma unroll
+  for (int i = 0; i < FA; ++i)
+#pragma unroll
+    for (int j = 0; j < FG; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t nrows = v_end > v_begin ? v_end - v_begin : 0;
+  const uint32_t l_bytes = (uint32_t)(nrows * d.ldl * 2);
+  const __bf16* lp = reinterpret_cast<const __bf16*>(d.l);
+  const __amdgpu_buffer_rsrc_t rl_ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(lp) + v_begin * d.ldl, 0, l_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(reinterpret_cast<const __bf16*>(d.g)), 0, p.g_bytes, 0x00020000);
+
+  u32x4 rl0[PASS], rg0[PASS], rl1[PASS], rg1[PASS];
+  const int tq = tid % TPR, tr = tid / TPR;
+  const bool a_col_ok = (a0 + tq * 8) < d.Ca;     // Ca % 8 == 0
+  const bool g_col_ok = (c0 + tq * 8) < d.Cg;
+  const uint32_t a_cb = (uint32_t)(a0 + tq * 8) * 2u, g_cb = (uint32_t)(c0 + tq * 8) * 2u;
+  const uint32_t ldlb = (uint32_t)d.ldl * 2u, ldgb = (uint32_t)d.ldg * 2u;
+
+  auto issue_loads = [&](uint32_t rbase, u32x4 (&rl)[PASS], u32x4 (&rg)[PASS]) {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const uint32_t row = rbase + tr + i * RPP;
+      rl[i] = __builtin_amdgcn_raw_buffer_load_b128(rl_, a_col_ok ? row * ldlb + a_cb : l_bytes, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const uint32_t row = rbase + tr + i * RPP;
+      const uint32_t v = (uint32_t)v_begin + row;
+      const uint32_t n = mdiv(v, p.mg_vox);
+      uint32_t rem = v - n * lvox;
+      const uint32_t od = mdiv(rem, p.mg_hw);
+      rem -= od * lhw;
+      const uint32_t oh = mdiv(rem, p.mg_w);
+      const uint32_t ow = rem - oh * d.Lw;
+      const int id = (int)od * d.sd + dd, ih = (int)oh * d.sh + dh, iw = (int)ow * d.sw + dw;
+      const bool inb = ((unsigned)id < (unsigned)d.Dg) & ((unsigned)ih < (unsigned)d.Hg) &
+                       ((unsigned)iw < (unsigned)d.Wg) & (row < (uint32_t)nrows) & g_col_ok;
+      const uint32_t gv = ((n * d.Dg + id) * d.Hg + ih) * d.Wg + iw;
+      rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg_, inb ? gv * ldgb + g_cb : p.g_bytes, 0, 0);
+    }
+  };
+  auto commit_loads = [&](int buf, const u32x4 (&rl)[PASS], const u32x4 (&rg)[PASS]) {
+    unsigned char* l = Ls + buf * BKV * ROW;
+    unsigned char* g = Gs + buf * BKV * ROW;
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) *reinterpret_cast<u32x4*>(l + (tr + i * RPP) * ROW + tq * 16) = rl[i];
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) *reinterpret_cast<u32x4*>(g + (tr + i * RPP) * ROW + tq * 16) = rg[i];
+  };
+
+  const int nsteps = (int)((nrows + BKV - 1) / BKV);
+  // transposed fragment reads: 16-lane group -> (k half h, channel half cg); lane 4q+pp supplies voxel row q, channels 4pp..
+  const int grp = lane >> 4, h = grp >> 1, cg = grp & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  const int lrow = 8 * h + q;
+  const int lcolA = (wa * WTA + 16 * cg + 4 * pp) * 2, lcolG = (wg * WTG + 16 * cg + 4 * pp) * 2;
+  auto frag = [&](const unsigned char* img, int kk, int colb) -> bf16x8 {
+    const unsigned char* a = img + (kk * 16 + lrow) * ROW + colb;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * ROW));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* l = Ls + buf * BKV * ROW;
+    const unsigned char* g = Gs + buf * BKV * ROW;
+#pragma unroll
+    for (int kk = wk * KSTEPS; kk < (wk + 1) * KSTEPS; ++kk) {
+      bf16x8 fa[FA], fg[FG];
+#pragma unroll
+      for (int i = 0; i < FA; ++i) fa[i] = frag(l, kk, lcolA + 64 * i);
+#pragma unroll
+      for (int j = 0; j < FG; ++j) fg[j] = frag(g, kk, lcolG + 64 * j);
+#pragma unroll
+      for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FG; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fg[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nsteps > 0) {
+    issue_loads(0, rl0, rg0);
+    issue_loads(BKV, rl1, rg1);
+    commit_loads(0, rl0, rg0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 2) {
+    issue_loads((uint32_t)(s + 2) * BKV, rl0, rg0);
+    compute(0);
+    commit_loads(1, rl1, rg1);
+    __syncthreads();
+    if (s + 1 >= nsteps) break;
+    issue_loads((uint32_t)(s + 3) * BKV, rl1, rg1);
+    compute(1);
+    commit_loads(0, rl0, rg0);
+    __syncthreads();
+  }
+
+  if (WGK > 1) {
+    float* red = reinterpret_cast<float*>(smem_b);  // [WGK-1][FA*FG*16][64]
+    constexpr int PER = FA * FG * 16;
+    __syncthreads();
+    if (wk > 0) {
+      float* o = red + (int64_t)(wk - 1) * PER * 64;
+#pragma unroll
+      for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FG; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[((i * FG + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+    for (int k = 0; k < WGK - 1; ++k) {
+      const float* o = red + (int64_t)k * PER * 64;
+#pragma unroll
+      for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FG; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += o[((i * FG + j) * 16 + r) * 64 + lane];
+    }
+  }
+  float* slab = d.workspace + (((int64_t)split * p.T + tap) * p.Capad) * p.Cgpad;
+  const int chalf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < FA; ++i)
+#pragma unroll
+    for (int j = 0; j < FG; ++j) {
+      const int col = c0 + wg * WTG + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * WTA + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+        slab[(int64_t)row * p.Cgpad + col] = acc[i][j][r];
+      }
+    }
+}
+
+template <int B, int WGA, int WGG, int BKV>
+int launch_wg_bf16(const WGParams& p, hipStream_t stream) {
+  constexpr int ROW = B * 2 + (B == 32 ? 0 : 64);
+  size_t smem = (size_t)4 * BKV * ROW;
+  constexpr int WGK = 4 / (WGA * WGG);
+  constexpr size_t red = (size_t)(WGK - 1) * ((B / WGA / 32) * (B / WGG / 32) * 16) * 64 * 4;
+  if (red > smem) smem = red;
+  auto kern = wgrad_bf16_kernel<B, WGA, WGG, BKV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return REHR_EHIP;
+    attr_set = true;
+  }
+  dim3 grid(p.T * p.a_tiles * p.c_tiles, p.splits, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), smem, stream, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+
 int tile_for(int c) { return (c % 128 == 0) ? 128 : ((c % 64 == 0) ? 64 : 32); }  // c % 32 != 0 -> masked 32-tiles
 int bkv_for(int t) { return t == 128 ? 32 : 64; }
 
 // 0 ok, else REHR_* code
-int plan(const rehr_wgrad_desc& d, WGParams& p) {
+int plan(const rehr_wgrad_desc& d, WGParams& p, int es = 4) {
   if (!d.l || !d.g || !d.dst) return REHR_EINVAL;
   if (d.Ca < 4 || d.Ca % 4 || d.Cg < 4 || d.Cg % 4) return REHR_EINVAL;  // tiles are padded, columns masked
   if (d.ldl % 4 || d.ldg % 4) return REHR_EINVAL;
@@ -302,10 +517,10 @@ int plan(const rehr_wgrad_desc& d, WGParams& p) {
   p.Capad = p.a_tiles * t;
   p.Cgpad = p.c_tiles * t;
   p.kv_total = (int64_t)d.N * d.Ld * d.Lh * d.Lw;
-  const int64_t gbytes = (int64_t)d.N * d.Dg * d.Hg * d.Wg * d.ldg * 4;
+  const int64_t gbytes = (int64_t)d.N * d.Dg * d.Hg * d.Wg * d.ldg * es;
   if (p.kv_total >= (1ll << 31) - 4096 || gbytes >= (1ll << 32) - 64) return REHR_ENOSUP;
   p.g_bytes = (uint32_t)gbytes;
-  const int bkv = bkv_for(t);
+  const int bkv = es == 2 ? 64 : bkv_for(t);
   const int64_t tiles = (int64_t)p.T * p.a_tiles * p.c_tiles;
   // aim for ~4 blocks per CU-slot (256 CUs x 2 resident) with >= 16 K steps each
   int64_t want = (2048 + tiles - 1) / tiles;
@@ -330,7 +545,7 @@ int plan(const rehr_wgrad_desc& d, WGParams& p) {
   }
   int64_t per = (p.kv_total + want - 1) / want;
   per = (per + bkv - 1) / bkv * bkv;
-  if ((int64_t)per * d.ldl * 4 >= (1ll << 32) - 64) return REHR_ENOSUP;
+  if ((int64_t)per * d.ldl * es >= (1ll << 32) - 64) return REHR_ENOSUP;
   p.kv_per_split = per;
   p.splits = (int)((p.kv_total + per - 1) / per);
   p.mg_vox = make_magic((uint32_t)(d.Ld * d.Lh * d.Lw));
@@ -365,7 +580,46 @@ int launch_wg(const WGParams& p, hipStream_t stream) {
   return REHR_OK;
 }
 
+int plan_bf16(const rehr_wgrad_desc& d, WGParams& p) {
+  if (d.Ca % 8 || d.Cg % 8 || d.ldl % 8 || d.ldg % 8 || d.dbias != nullptr) return REHR_EINVAL;
+  return plan(d, p, 2);
+}
+
 }  // namespace
+
+extern "C" int64_t rehr_wgrad_bf16_workspace_bytes(const rehr_wgrad_desc* dp) {
+  if (!dp) return REHR_EINVAL;
+  WGParams p;
+  rehr_wgrad_desc d = *dp;
+  if (!d.dst) d.dst = reinterpret_cast<float*>(16);
+  const int rc = plan_bf16(d, p);
+  if (rc != REHR_OK) return rc;
+  return (int64_t)p.splits * p.T * p.Capad * p.Cgpad * (int64_t)sizeof(float);
+}
+
+extern "C" int rehr_wgrad_bf16(const rehr_wgrad_desc* dp, void* stream) {
+  if (!dp) return REHR_EINVAL;
+  WGParams p;
+  int rc = plan_bf16(*dp, p);
+  if (rc != REHR_OK) return rc;
+  const rehr_wgrad_desc& d = p.d;
+  if (!d.workspace || d.workspace_bytes < (int64_t)p.splits * p.T * p.Capad * p.Cgpad * (int64_t)sizeof(float))
+    return REHR_EINVAL;
+  if (p.splits > 65535) return REHR_EINVAL;
+  p.slab_bias = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int t = p.Capad / p.a_tiles;
+  if (t == 128) rc = launch_wg_bf16<128, 2, 2, 64>(p, st);
+  else if (t == 64) rc = launch_wg_bf16<64, 1, 1, 64>(p, st);
+  else rc = launch_wg_bf16<32, 1, 1, 64>(p, st);
+  if (rc != REHR_OK) return rc;
+  const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
 
 extern "C" int64_t rehr_wgrad_workspace_bytes(const rehr_wgrad_desc* dp) {
   if (!dp) return REHR_EINVAL;

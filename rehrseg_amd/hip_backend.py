@@ -111,6 +111,18 @@ def _chk_dev(*ts, f64=()):
             raise L.RehrsegHipError("statistics buffers are float64 device tensors")
 
 
+def _fn(base, t):
+    """C entry point `base`_f32 or `base`_bf16 by the dtype of activation tensor `t`."""
+    name = base + ("_bf16" if t.dtype == torch.bfloat16 else "_f32")
+    return getattr(L.load(), name), name
+
+
+def _same_dtype(*ts):
+    dts = {t.dtype for t in ts if t is not None}
+    if len(dts) > 1:
+        raise L.RehrsegHipError(f"activation operands of one call must share a dtype, got {sorted(map(str, dts))}")
+
+
 def new_act(N, Cc, D, H, W, like, zero=False, dtype=None):
     """NDHWC activation in `like`'s dtype (fp32, or bf16 on the mixed-precision path) unless `dtype` says otherwise."""
     dt = dtype if dtype is not None else (like.dtype if like.dtype == torch.bfloat16 else torch.float32)
@@ -242,7 +254,11 @@ def sum_slabs_bias_act(slabs, S, bias, act, slope, stats=None):
 
 
 def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, dst_strides, accumulate, dbias):
+    """dst (fp32, the master-weight gradient) from l / g in fp32, or both in bf16 (mixed precision: no dbias)."""
     _chk_dev(l, g, dst, dbias)
+    bf16 = l.dtype == torch.bfloat16
+    if (g.dtype == torch.bfloat16) != bf16 or dst.dtype != torch.float32:
+        raise L.RehrsegHipError("weight gradient: l and g share one dtype (fp32 or bf16), dst is float32")
     d = L.WgradDesc()
     d.l, d.ldl, d.Ca = _ptr(l), l.shape[1], Ca
     d.g, d.ldg, d.Cg = _ptr(g), g.shape[1], Cg
@@ -259,6 +275,18 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     d.dbias = _ptr(dbias)
     d.flags = 0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT
     lib = L.load()
+    flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
+    if bf16:
+        if dbias is not None:
+            raise L.RehrsegHipError("mixed-precision weight gradient has no fused bias gradient (use channel_sum)")
+        nbytes = lib.rehr_wgrad_bf16_workspace_bytes(C.byref(d))
+        if nbytes < 0:
+            L.check(int(nbytes), "rehr_wgrad_bf16_workspace_bytes")
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
+        d.workspace, d.workspace_bytes = _ptr(ws), nbytes
+        with _timed("wgrad_bf16", flops):
+            L.check(lib.rehr_wgrad_bf16(C.byref(d), _stream()), "rehr_wgrad_bf16")
+        return
     nbytes = lib.rehr_wgrad_workspace_bytes(C.byref(d))
     if nbytes < 0:
         L.check(int(nbytes), "rehr_wgrad_workspace_bytes")
@@ -267,7 +295,6 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     wino_wgrad_launches += wino
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
     d.workspace, d.workspace_bytes = _ptr(ws), nbytes
-    flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
     with _timed(("wino_wgrad" if d.th.count == 3 else "wino22_wgrad") if wino else "wgrad", flops):
         L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
 
@@ -364,22 +391,24 @@ def _nsc(x):
 
 def scale_res_act_fwd(x, gate, res, act, slope):
     _chk_dev(x, gate, res)
+    _same_dtype(x, res)
     N, S, Cc = _nsc(x)
     y = new_act(*x.shape, like=x)
-    L.check(L.load().rehr_scale_res_act_fwd_f32(_ptr(x), Cc, _ptr(gate), _ptr(res), Cc, _ptr(y), Cc, N, S, Cc,
-                                                act, slope, _stream()), "rehr_scale_res_act_fwd_f32")
+    fn, name = _fn("rehr_scale_res_act_fwd", x)
+    L.check(fn(_ptr(x), Cc, _ptr(gate), _ptr(res), Cc, _ptr(y), Cc, N, S, Cc, act, slope, _stream()), name)
     return y
 
 
 def scale_res_act_bwd(dy, y, x, gate, want_dres, act, slope):
     _chk_dev(dy, y, x, gate)
+    _same_dtype(dy, y, x)
     N, S, Cc = _nsc(x)
     dx = new_act(*x.shape, like=x)
     dres = new_act(*x.shape, like=x) if want_dres else None
     dgate = torch.zeros((N, Cc), dtype=torch.float64, device=x.device)
-    L.check(L.load().rehr_scale_res_act_bwd_f32(_ptr(dy), Cc, _ptr(y), Cc, _ptr(x), Cc, _ptr(gate), _ptr(dx), Cc,
-                                                _ptr(dres), Cc, _ptr(dgate), N, S, Cc, act, slope, _stream()),
-            "rehr_scale_res_act_bwd_f32")
+    fn, name = _fn("rehr_scale_res_act_bwd", x)
+    L.check(fn(_ptr(dy), Cc, _ptr(y), Cc, _ptr(x), Cc, _ptr(gate), _ptr(dx), Cc, _ptr(dres), Cc, _ptr(dgate), N, S, Cc,
+               act, slope, _stream()), name)
     return dx, dres, dgate
 
 
@@ -397,8 +426,8 @@ def se_gate_bwd(dgate, gate, mean, w, S):
 def add_channel_const(x, k):
     _chk_dev(x, k)
     N, S, Cc = _nsc(x)
-    L.check(L.load().rehr_add_channel_const_f32(_ptr(x), Cc, _ptr(k), N, S, Cc, _stream()),
-            "rehr_add_channel_const_f32")
+    fn, name = _fn("rehr_add_channel_const", x)
+    L.check(fn(_ptr(x), Cc, _ptr(k), N, S, Cc, _stream()), name)
 
 
 def instnorm_act_fwd(x, stats, gamma, beta, eps, act, slope):
@@ -406,22 +435,23 @@ def instnorm_act_fwd(x, stats, gamma, beta, eps, act, slope):
     N, S, Cc = _nsc(x)
     y = new_act(*x.shape, like=x)
     mr = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
-    L.check(L.load().rehr_instnorm_act_fwd_f32(_ptr(x), Cc, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(y), Cc,
-                                               _ptr(mr), N, S, Cc, eps, act, slope, _stream()),
-            "rehr_instnorm_act_fwd_f32")
+    fn, name = _fn("rehr_instnorm_act_fwd", x)
+    L.check(fn(_ptr(x), Cc, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(y), Cc, _ptr(mr), N, S, Cc, eps, act, slope,
+               _stream()), name)
     return y, mr
 
 
 def instnorm_act_bwd(dy, x, mr, gamma, beta, act, slope):
     _chk_dev(dy, x, mr, gamma, beta)
+    _same_dtype(dy, x)
     N, S, Cc = _nsc(x)
     dx = new_act(*x.shape, like=x)
     dg = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     red = torch.zeros((N, Cc, 2), dtype=torch.float64, device=x.device)
-    L.check(L.load().rehr_instnorm_act_bwd_f32(_ptr(dy), Cc, _ptr(x), Cc, _ptr(mr), _ptr(gamma), _ptr(beta),
-                                               _ptr(dx), Cc, _ptr(dg), _ptr(db), _ptr(red), N, S, Cc, act, slope,
-                                               _stream()), "rehr_instnorm_act_bwd_f32")
+    fn, name = _fn("rehr_instnorm_act_bwd", x)
+    L.check(fn(_ptr(dy), Cc, _ptr(x), Cc, _ptr(mr), _ptr(gamma), _ptr(beta), _ptr(dx), Cc, _ptr(dg), _ptr(db), _ptr(red),
+               N, S, Cc, act, slope, _stream()), name)
     return dx, dg, db
 
 
@@ -535,9 +565,10 @@ def act_fwd(x, act, slope):
 
 def act_bwd(dy, y, act, slope):
     _chk_dev(dy, y)
+    _same_dtype(dy, y)
     dx = torch.empty_like(y)
-    L.check(L.load().rehr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), act, slope, _stream()),
-            "rehr_act_bwd_f32")
+    fn, name = _fn("rehr_act_bwd", y)
+    L.check(fn(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), act, slope, _stream()), name)
     return dx
 
 
@@ -546,8 +577,8 @@ def channel_sum(x):
     N, S, Cc = _nsc(x)
     out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     scratch = torch.empty((Cc,), dtype=torch.float64, device=x.device)
-    L.check(L.load().rehr_channel_sum_f32(_ptr(x), Cc, N * S, Cc, _ptr(out), 0, _ptr(scratch), _stream()),
-            "rehr_channel_sum_f32")
+    fn, name = _fn("rehr_channel_sum", x)
+    L.check(fn(_ptr(x), Cc, N * S, Cc, _ptr(out), 0, _ptr(scratch), _stream()), name)
     return out
 
 

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "rehr_wgrad_workspace_bytes": (_i64, [_P_WG]),
     "rehr_wgrad_uses_winograd": (C.c_int, [_P_WG]),
     "rehr_wgrad_f32": (C.c_int, [_P_WG, _vp]),
+    "rehr_wgrad_bf16_workspace_bytes": (_i64, [_P_WG]),
+    "rehr_wgrad_bf16": (C.c_int, [_P_WG, _vp]),
     "rehr_pack_weights_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "rehr_conv_small_cin_fwd_f32": (C.c_int, [_P_DC, _vp]),
     "rehr_im2col_f32": (C.c_int, [_P_DC, _vp, _i32, _vp]),
@@ -131,6 +133,16 @@ PROTOTYPES = {
     "rehr_copy_channels_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "rehr_nchw_to_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "rehr_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
+    "rehr_scale_res_act_fwd_bf16": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp]),
+    "rehr_scale_res_act_bwd_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp,
+                                              _i32, _i64, _i32, _i32, _f32, _vp]),
+    "rehr_add_channel_const_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
+    "rehr_instnorm_act_fwd_bf16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _f32,
+                                             _i32, _f32, _vp]),
+    "rehr_instnorm_act_bwd_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                             _i32, _i64, _i32, _i32, _f32, _vp]),
+    "rehr_channel_sum_bf16": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "rehr_act_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "rehr_abi_version": (C.c_int, []),
     "rehr_last_hip_error": (C.c_char_p, []),
 }

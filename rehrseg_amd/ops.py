@@ -43,6 +43,36 @@ def set_backend(b):
     return old
 
 
+# ----------------------------------------------------------------------------- mixed precision
+# BASELINE.json configs[4]: "bf16 mixed precision ... MFMA implicit-GEMM path".  Inside `mixed_precision()` every
+# matrix-core convolution (and the SEGating / InstanceNorm tail fused behind it) takes bf16 activations and a bf16
+# copy of the fp32 master weights, accumulates in fp32, forms its statistics in fp32/fp64 and returns bf16
+# activations; gradients of activations are bf16, weight gradients fp32.  The thin layers (1-2 input channels,
+# <= 4 output channels), the depth upsample and the losses stay fp32 -- the same split torch.autocast makes.
+_mixed = False
+
+
+class mixed_precision:
+    """Context manager: run the matrix-core convolutions in bf16 (fp32 accumulate, fp32 master weights)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _mixed
+        self.prev, _mixed = _mixed, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _mixed
+        _mixed = self.prev
+        return False
+
+
+def is_mixed_precision():
+    return _mixed
+
+
 # ----------------------------------------------------------------------------- layout
 def to_cl(x: torch.Tensor) -> torch.Tensor:
     """Logical (N,C,D,H,W) tensor whose memory is NDHWC-dense; fp32, or bf16 on the mixed-precision path."""
@@ -397,6 +427,7 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
     db = None
     taps = [full_taps(k) for k in K]
     b = tuple(-p for p in cfg.pad)
+    fused_bias = dz.dtype != torch.bfloat16   # the mixed-precision kernel leaves the bias gradient to a column sum
     if cfg.transposed:
         # lattice = input x (rows of w), gathered = dY (cols of w)
         Cout = w.shape[1]
@@ -412,7 +443,7 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
             db = be.channel_sum(dz)
     else:
         Cout = w.shape[0]
-        db = torch.empty((Cout,), dtype=w.dtype, device=w.device) if want_bias else None
+        db = torch.empty((Cout,), dtype=w.dtype, device=w.device) if (want_bias and fused_bias) else None
         lo = 0
         first = True
         for xs in (x1, x2):
@@ -423,6 +454,8 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
                      (Cin * T, T, 1), False, db if first else None)
             first = False
             lo += cnt
+        if want_bias and not fused_bias:
+            db = be.channel_sum(dz)
     return dw, db
 
 
@@ -515,6 +548,14 @@ def fused_conv3d(x, w, b=None, stride=1, padding=0, *, x2=None, transposed=False
         raise ValueError("res is only fused behind SEGating")
     cfg = ConvCfg(_triple(stride), _triple(padding), bool(transposed), int(act), float(slope), mode, float(eps))
     p1, p2 = (se if se is not None else (inorm if inorm is not None else (None, None)))
+    # operand dtype: the thin layers are fp32 kernels; the matrix-core layers follow mixed_precision() / their input
+    cin = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    thin = cin <= 2 or _thin_out(w, cfg, x2 is not None)
+    want = torch.float32 if thin else (torch.bfloat16 if (_mixed or x.dtype == torch.bfloat16) else x.dtype)
+    if want in (torch.float32, torch.bfloat16):
+        x = x if x.dtype == want else x.to(want)
+        x2 = x2 if (x2 is None or x2.dtype == want) else x2.to(want)
+        res = res if (res is None or res.dtype == want) else res.to(want)
     return _FusedConv.apply(x, x2, w, b, p1, p2, res, cfg)
 
 
@@ -563,6 +604,8 @@ def upsample_conv3d_depth(x, w, b, scale, act=ACT_NONE, slope=0.0):
     Do = int(x.shape[2] * scale)
     wg = w.permute(2, 0, 1, 3, 4).reshape(KD * Cout, Cin, 1, KH, KW)  # row kd*Cout + co
     g = fused_conv3d(x, wg, None, 1, (0, KH // 2, KW // 2))
+    if g.dtype != torch.float32:   # mixed precision: the per-tap responses come back bf16, the HR head stays fp32
+        g = g.float()
     return _UpMixDepth.apply(g, b, Do, Cout, KD, KD // 2, int(act), float(slope))
 
 

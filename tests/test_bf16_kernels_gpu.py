@@ -87,3 +87,33 @@ def test_conv_transpose3d_bf16(K, s, p):
     xr = x.double().requires_grad_()
     F.conv_transpose3d(xr, w.to(BF).double(), None, s, p).backward(dz.double())
     assert relmax(dx, xr.grad) < 1e-2
+
+
+WG_CASES = [  # (N, Cin, Cout, D, H, W, kernel, stride, pad, transposed)
+    (2, 64, 64, 6, 20, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), False),     # 64-tile, waves split K
+    (1, 128, 128, 4, 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), False),   # 128-tile, 2x2 waves
+    (2, 32, 32, 5, 18, 22, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),     # 32-tile
+    (1, 32, 64, 8, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), False),     # strided, mixed channel counts
+    (1, 48, 96, 4, 10, 12, (3, 3, 3), (1, 1, 1), (1, 1, 1), False),     # masked tiles
+    (1, 128, 64, 4, 8, 8, (2, 2, 2), (2, 2, 2), (0, 0, 0), True),       # ConvTranspose3d, kernel = stride
+    (1, 128, 64, 4, 8, 8, (3, 4, 4), (1, 2, 2), (1, 1, 1), True),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_weight_gradient_bf16(case):
+    N, Cin, Cout, D, H, W, K, s, p, tr = case
+    g = torch.Generator().manual_seed(sum(case[:6]) + 1)
+    x = act((N, Cin, D, H, W), g)
+    wshape = ((Cin, Cout) if tr else (Cout, Cin)) + K
+    w = (torch.randn(wshape, generator=g) * 0.05).to(DEV)
+    cfg = ops.ConvCfg(s, p, transposed=tr)
+    conv = (lambda a, ww: F.conv_transpose3d(a, ww, None, s, p)) if tr else (lambda a, ww: F.conv3d(a, ww, None, s, p))
+    wr = w.double().requires_grad_()
+    ref_y = conv(x.double(), wr)
+    dz = act(tuple(ref_y.shape), g)
+    ref_y.backward(dz.double())
+    dw, db = ops.conv_wgrad(dz, x, None, w, cfg, True)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == wshape
+    assert relmax(dw, wr.grad) < 1e-4      # exact bf16 products, fp32 accumulation: only the summation order differs
+    assert relmax(db, dz.double().sum((0, 2, 3, 4))) < 1e-4

@@ -152,15 +152,32 @@ def test_cfg3_segmodel_128cube_against_cpu_reference_path():
     torch.cuda.empty_cache()
 
     runs = {}
+    N = x.shape[0]
     for dt in (torch.float32, torch.float64):
         with heartbeat("cfg3"):
             t0 = time.time()
             osd = {k: v.detach().clone().to(dt).requires_grad_() for k, v in sd.items() if k in so.segmodel_shapes(so.ISO_PLAN)}
-            r_out, r_up = so.seg_model(osd, x.to(dt), so.ISO_PLAN)
-            rl = ao.dc_and_weighted_ce(r_out, lab_lr.to(dt)) + ao.dc_and_weighted_ce(r_up, lab_hr.to(dt))
-            rl.backward()
-            runs[dt] = (r_out.detach(), r_up.detach(), float(rl.detach()), {k: v.grad for k, v in osd.items()})
-            del r_out, r_up, rl, osd
+            if dt == torch.float32:   # the reference CPU path as it runs: the whole batch at once
+                r_out, r_up = so.seg_model(osd, x.to(dt), so.ISO_PLAN)
+                rl = ao.dc_and_weighted_ce(r_out, lab_lr.to(dt)) + ao.dc_and_weighted_ce(r_up, lab_hr.to(dt))
+                rl.backward()
+                runs[dt] = (r_out.detach(), r_up.detach(), float(rl.detach()), {k: v.grad for k, v in osd.items()})
+                del r_out, r_up, rl
+            else:
+                # fp64 yardstick, one sample at a time: ATen's double-precision Conv3d on the CPU unfolds its input
+                # (27 x C_in columns per voxel: 116 GB for sr_head.0 on the 2x32x512x128x128 tensor), and nothing in
+                # the model or the loss couples samples (InstanceNorm and soft Dice are per sample, CE is a mean),
+                # so the batch loss is the mean of the per-sample losses and the gradients add up.
+                tot = 0.0
+                for b in range(N):
+                    o_b, u_b = so.seg_model(osd, x[b:b + 1].to(dt), so.ISO_PLAN)
+                    l_b = (ao.dc_and_weighted_ce(o_b, lab_lr[b:b + 1].to(dt)) +
+                           ao.dc_and_weighted_ce(u_b, lab_hr[b:b + 1].to(dt))) / N
+                    l_b.backward()
+                    tot += float(l_b.detach())
+                    del o_b, u_b, l_b
+                runs[dt] = (None, None, tot, {k: v.grad for k, v in osd.items()})
+            del osd
             print(f"[cfg3] oracle {dt} step: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
     r_out, r_up, l32, g32 = runs[torch.float32]
     fwd = max(float((a - b).abs().max() / b.abs().max()) for a, b in ((out_c, r_out), (up_c, r_up)))
