@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16)
 
 
 def build_model(n_inputs, dev):
@@ -96,7 +97,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=128, help="patch edge (128 = BASELINE config)")
-    ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref", "cfg4"], default="flavr",
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
+                    help="bf16 = ops.mixed_precision(): bf16 operands on the matrix cores, fp32 accumulate / statistics / "
+                         "master weights (BASELINE.json configs[4]); default fp32 (bf16 for --workload cfg5)")
+    ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref", "cfg4", "cfg5"], default="flavr",
                     help="flavr = configs[1] (headline); seg = configs[2] (SegModel 2x1x128^3, secondary); "
                          "flavr_ref = the reference's own stage-1 training shape, UNet_3D_3D(2,..,4,4) on "
                          "(B,2,4,96,96) with the UASR head (configs/brain.yaml)")
@@ -121,6 +125,16 @@ def main():
     from rehrseg_amd import hip_backend
     from rehrseg_amd.parallel import PatchParallel
 
+    if args.workload == "cfg5":   # BASELINE.json configs[4]: the joint step in bf16 mixed precision at 160^3
+        args.workload = "cfg4"
+        args.precision = args.precision or "bf16"
+        if args.size == 128:
+            args.size = 160
+        cfg5 = True
+    else:
+        cfg5 = False
+    mixed = args.precision == "bf16"
+    from rehrseg_amd import ops
     size = args.size
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # every rank draws its own patch
     if args.workload == "flavr":
@@ -223,10 +237,17 @@ def main():
             opt.step()
             return loss
 
+    if mixed:
+        plain_step = step
+
+        def step():
+            with ops.mixed_precision():
+                return plain_step()
+        workload = "[bf16 mixed precision: bf16 MFMA operands, fp32 accumulate / statistics / master weights] " + workload
     # CPU leg FIRST (rank 0, N=1, headline workload): the oracle on the host cores with the GPU model's own initial
     # weights and patch; its warm-up step doubles as the parity check of the HIP forward (north_star: within 1e-3).
     cpu_rec = parity = None
-    if world == 1 and not args.no_cpu_baseline and args.workload == "flavr":
+    if world == 1 and not args.no_cpu_baseline and args.workload == "flavr" and not mixed:
         sd0 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         cpu_rec, (ref_out, ref_loss) = cpu_baseline(size, sd0, x.cpu(), tgt.cpu(), args.cpu_steps)
         with torch.no_grad():
@@ -259,9 +280,10 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         rec = {
-            "metric": "3D patches/sec (fwd+bwd, 128^3 fp32)", "value": world * patches_per_step * args.steps / elapsed,
+            "metric": f"3D patches/sec (fwd+bwd, {size}^3 {'bf16 mixed precision' if mixed else 'fp32'})", "value": world * patches_per_step * args.steps / elapsed,
             "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if mixed else "f32",
+            "data": "synthetic",
             "config": {"workload": workload, "patches_per_gpu": patches_per_step,
                        "global_batch": world * patches_per_step,
                        "parallelism": f"dp{world} (patch-parallel, flat-bucket RCCL all-reduce)"},
@@ -269,7 +291,8 @@ def main():
         }
         EXEC = {"wino_conv": 16.0 / 36.0, "wino_wgrad": 16.0 / 36.0,      # F(2x2,3x3): 16 of 36 products issued
                 "wino22_conv": 9.0 / 16.0, "wino22_wgrad": 9.0 / 16.0,    # F(2x2,2x2): 9 of 16
-                "gather_gemm": 1.0, "wgrad": 1.0}
+                "gather_gemm": 1.0, "wgrad": 1.0, "gather_gemm_bf16": 1.0, "wgrad_bf16": 1.0}
+        PEAK = {"gather_gemm_bf16": BF16_MFMA_PEAK_TFLOPS, "wgrad_bf16": BF16_MFMA_PEAK_TFLOPS}
 
         def fam(name):
             """Roofline record of a kernel family.  `achieved` / `frac` price the MFMA work the kernels ISSUE
@@ -280,9 +303,10 @@ def main():
                 return None
             alg = f["flops"] / f["seconds"] / 1e12
             ex = alg * EXEC[name]
-            return {"bound": "mfma", "achieved": ex, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ex / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "algorithmic_achieved": alg, "algorithmic_frac": alg / FP32_MFMA_PEAK_TFLOPS,
+            peak = PEAK.get(name, FP32_MFMA_PEAK_TFLOPS)
+            return {"bound": "mfma", "achieved": ex, "peak": peak, "unit": "TFLOP/s",
+                    "frac": ex / peak, "traffic": None,
+                    "algorithmic_achieved": alg, "algorithmic_frac": alg / peak,
                     "mfma_products_issued_per_algorithmic": EXEC[name],
                     "launches_per_step": f["launches"] / args.steps,
                     "avg_launch_ms": f["seconds"] / f["launches"] * 1e3,
@@ -292,7 +316,10 @@ def main():
         names = {"wino_conv": "wino_conv_big_kernel / wino_conv_w32_kernel / wino_conv_kernel / wino_flat_conv_kernel: "
                               "Winograd F(2x2,3x3)-over-(H,W) fp32 MFMA conv forward / input gradient",
                  "gather_gemm": "gather_gemm_kernel / halo_conv_kernel: fp32 MFMA implicit-GEMM conv (strided, 1x1x1, "
-                                "transposed phases)"}
+                                "transposed phases)",
+                 "gather_gemm_bf16": "gather_gemm_bf16_kernel: bf16-operand / fp32-accumulate implicit-GEMM conv forward, "
+                                     "input gradient, transposed-conv phases (v_mfma_f32_32x32x16_bf16)",
+                 "wgrad_bf16": "wgrad_bf16_kernel: bf16-operand / fp32-accumulate weight gradient"}
         fams = {n: fam(n) for n in EXEC}
         dominant = max((n for n in fams if fams[n]), key=lambda n: fams[n]["ms_per_step"], default=None)
         if dominant:

@@ -323,11 +323,14 @@ class Distiller(nn.Module):
         self.distill = nn.Conv3d(student_dim, teacher_dim, kernel_size=1, stride=1, padding=0)
 
     def forward(self, feature_student, feature_teacher):
+        """bf16 features (ops.mixed_precision): the 1x1x1 projection runs on the bf16 matrix cores, the structure /
+        cosine statistics on fp32 copies (`.float()` of an fp32 tensor is the tensor itself)."""
         loss = 0
+        feature_teacher = feature_teacher.float()
         if self.lambda_structure > 0:
-            loss = loss + self.lambda_structure * self.criterion_structure(feature_student, feature_teacher)
+            loss = loss + self.lambda_structure * self.criterion_structure(feature_student.float(), feature_teacher)
         if feature_student.is_cuda:  # 1x1x1 conv on the MFMA path
-            distilled = ops.fused_conv3d(feature_student, self.distill.weight, self.distill.bias, 1, 0)
+            distilled = ops.fused_conv3d(feature_student, self.distill.weight, self.distill.bias, 1, 0).float()
         else:
             distilled = F.conv3d(feature_student, self.distill.weight, self.distill.bias)
         if self.lambda_l1 > 0:
