@@ -104,6 +104,8 @@ typedef struct {
 
 /* bf16 entry points: store y as fp32 instead of bf16 (logits, features handed to fp32 losses) */
 #define REHR_GG_Y_F32 1
+/* bf16 entry points: never take the LDS halo-brick kernel (tests compare it with the per-tap gather kernel) */
+#define REHR_GG_NO_HALO 2
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);

@@ -19,6 +19,8 @@
 //    in the fp32 kernel.
 #include "common.h"
 
+int halo_conv_bf16_try(const rehr_gather_gemm_desc& d, hipStream_t stream);  // halo_conv_bf16.hip
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -442,16 +444,24 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ in, __bf16* _
 extern "C" int rehr_gather_gemm_multi_bf16(const rehr_gather_gemm_desc* descs, int32_t count, void* stream) {
   if (descs == nullptr || count < 1 || count > MAX_PHASES) return REHR_EINVAL;
   GBMulti pm;
+  int n = 0;
   for (int i = 0; i < count; ++i) {
     int rc = validate(descs[i]);
     if (rc != REHR_OK) return rc;
     if (descs[i].Npad != descs[0].Npad || descs[i].N != descs[0].N || descs[i].wp != descs[0].wp ||
         descs[i].x1 != descs[0].x1 || descs[i].Cin != descs[0].Cin || descs[i].c1 != descs[0].c1)
       return REHR_EINVAL;
-    rc = plan(descs[i], pm.ph[i]);
+    if (!(descs[i].flags & REHR_GG_NO_HALO)) {   // unit-stride 3x3(x3) taps: input brick + halo staged in LDS
+      rc = halo_conv_bf16_try(descs[i], (hipStream_t)stream);
+      if (rc == REHR_OK) continue;
+      if (rc != REHR_ENOSUP) return rc;
+    }
+    rc = plan(descs[i], pm.ph[n]);
     if (rc != REHR_OK) return rc;
+    ++n;
   }
-  return launch_generic(pm, count, (hipStream_t)stream);
+  if (n == 0) return REHR_OK;
+  return launch_generic(pm, n, (hipStream_t)stream);
 }
 
 extern "C" int rehr_gather_gemm_bf16(const rehr_gather_gemm_desc* dp, void* stream) {

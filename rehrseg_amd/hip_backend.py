@@ -151,6 +151,7 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
 # Tests flip these to compare the transform-domain kernels with the direct ones.
 USE_WINOGRAD = True
 USE_WINOGRAD_WGRAD = True
+USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
 wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
 
@@ -186,7 +187,7 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             raise L.RehrsegHipError("mixed-precision gather-GEMM: x1, x2 and the packed weights must all be bfloat16")
         if bias is not None and bias.dtype != torch.float32:
             raise L.RehrsegHipError("bias stays float32")
-        d.flags = L.GG_Y_F32 if y.dtype == torch.float32 else 0
+        d.flags = (L.GG_Y_F32 if y.dtype == torch.float32 else 0) | (0 if USE_HALO_BF16 else L.GG_NO_HALO)
     elif wp.dtype != torch.float32 or y.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
         raise L.RehrsegHipError("fp32 gather-GEMM: every operand must be float32")
     elif USE_WINOGRAD and tile[0] >= 0:

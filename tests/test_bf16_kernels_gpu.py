@@ -117,3 +117,62 @@ def test_weight_gradient_bf16(case):
     assert dw.dtype == torch.float32 and tuple(dw.shape) == wshape
     assert relmax(dw, wr.grad) < 1e-4      # exact bf16 products, fp32 accumulation: only the summation order differs
     assert relmax(db, dz.double().sum((0, 2, 3, 4))) < 1e-4
+
+
+HALO_CASES = [  # shapes the LDS halo-brick kernel takes: (N, Cin, Cout, D, H, W, kernel, pad)
+    (1, 32, 32, 8, 16, 32, (3, 3, 3), (1, 1, 1)),      # BN 32: brick 4x8x16, one block per CU
+    (2, 32, 32, 5, 32, 32, (1, 3, 3), (0, 1, 1)),      # BN 32: brick 2x16x16? (Ld 5 -> 4x8x16 pads 1.6x) / 1x3x3 taps
+    (1, 64, 64, 4, 16, 32, (3, 3, 3), (1, 1, 1)),      # BN 64: brick 2x8x16
+    (1, 64, 64, 8, 8, 8, (3, 3, 3), (1, 1, 1)),        # BN 64: brick 4x8x8
+    (1, 128, 128, 4, 16, 16, (3, 3, 3), (1, 1, 1)),    # BN 128: brick 2x8x8, 4 chunks
+    (1, 48, 96, 6, 16, 32, (3, 3, 3), (1, 1, 1)),      # half-filled last chunk, padded N (96 -> 3 x 32)
+    (2, 320, 320, 4, 8, 8, (3, 3, 3), (1, 1, 1)),      # 10 chunks, 5 channel tiles of 64
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_halo_brick_kernel_matches_gather_kernel_and_torch(case):
+    from rehrseg_amd import hip_backend
+    N, Cin, Cout, D, H, W, K, p = case
+    g = torch.Generator().manual_seed(sum(case[:6]) + 3)
+    x = act((N, Cin, D, H, W), g)
+    w = (torch.randn((Cout, Cin) + K, generator=g) / (Cin * K[0] * 9) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    cfg = ops.ConvCfg((1, 1, 1), p)
+    res = {}
+    for halo in (True, False):
+        hip_backend.USE_HALO_BF16 = halo
+        try:
+            y, stats = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.1, 2)
+            dz = act(tuple(y.shape), torch.Generator().manual_seed(1))
+            dx, _ = ops.conv_dgrad(dz, w, (D, H, W), Cin, 0, cfg)
+        finally:
+            hip_backend.USE_HALO_BF16 = True
+        res[halo] = (y.float(), stats.clone(), dx.float())
+    wq = w.to(BF).double()
+    ref = F.leaky_relu(F.conv3d(x.double(), wq, b.double(), 1, p), 0.1)
+    xr = x.double().requires_grad_()
+    F.conv3d(xr, wq, None, 1, p).backward(dz.double())
+    for halo in (True, False):
+        y, stats, dx = res[halo]
+        assert relmax(y, ref) < 1e-2 and relmax(dx, xr.grad) < 1e-2, halo
+        assert relmax(stats[..., 0], ref.sum((2, 3, 4))) < 2e-3 and relmax(stats[..., 1], (ref ** 2).sum((2, 3, 4))) < 1e-3
+    # the two kernels form the same fp32 sums in a different order: identical after rounding to bf16 almost everywhere
+    assert relmax(res[True][0], res[False][0]) < 1e-2 and relmax(res[True][1], res[False][1]) < 1e-5
+
+
+def test_halo_brick_kernel_virtual_concat_and_transposed_phase_taps():
+    g = torch.Generator().manual_seed(21)
+    x1, x2 = act((1, 32, 4, 16, 32), g), act((1, 32, 4, 16, 32), g)
+    w = (torch.randn(32, 64, 3, 3, 3, generator=g) / (64 * 27) ** 0.5).to(DEV)
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1))
+    y, _ = ops.conv_forward(x1, x2, w, None, cfg, ops.ACT_NONE, 0.0, 0)
+    ref = F.conv3d(torch.cat([x1, x2], 1).double(), w.to(BF).double(), None, 1, 1)
+    assert relmax(y, ref) < 1e-2
+    # ConvTranspose3d (3,4,4)/(1,2,2): every output phase is a unit-stride 3x2x2-tap gather written at stride 2
+    xt = act((1, 64, 4, 16, 16), g)
+    wt = (torch.randn(64, 64, 3, 4, 4, generator=g) / (64 * 12) ** 0.5).to(DEV)
+    ct = ops.ConvCfg((1, 2, 2), (1, 1, 1), transposed=True)
+    yt, _ = ops.conv_forward(xt, None, wt, None, ct, ops.ACT_NONE, 0.0, 0)
+    rt = F.conv_transpose3d(xt.double(), wt.to(BF).double(), None, (1, 2, 2), (1, 1, 1))
+    assert relmax(yt, rt) < 1e-2
