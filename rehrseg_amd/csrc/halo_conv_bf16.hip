@@ -471,11 +471,12 @@ int launch(HBParams p, hipStream_t stream) {
   constexpr int ntaps = 3 * NT3;
   constexpr int XROWS = (((BD + 2) * (BH + 2) * (BW + 2) + RPP - 1) / RPP) * RPP;   // = MAXX * RPP in the kernel
   const size_t smem = (size_t)XROWS * XROW + (size_t)ntaps * BN * WROW + (size_t)BVOX * sizeof(int);
-  if (smem > 158 * 1024 || p.ntiles >= (1ll << 31) - 4096) return REHR_ENOSUP;
+  if (smem > 158 * 1024) return REHR_ENOSUP;
   if ((int64_t)d.N * d.Dy * d.Hy * d.Wy * d.ldy * 2 >= (1ll << 32) - 64) return REHR_ENOSUP;   // buffer-addressed stores
   p.nb_d = (int)nb_d; p.nb_h = (int)nb_h; p.nb_w = (int)nb_w;
   p.tiles_per_img = (int)(nb_d * nb_h * nb_w);
   p.ntiles = (int64_t)d.N * p.tiles_per_img;
+  if (p.ntiles >= (1ll << 31) - 4096) return REHR_ENOSUP;
   // persistent blocks, one per CU: whole rounds of 256
   const int n_tiles = d.Npad / BN;
   int64_t want = 256 / n_tiles;
