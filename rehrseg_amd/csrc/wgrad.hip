@@ -594,6 +594,10 @@ extern "C" int64_t rehr_wgrad_bf16_workspace_bytes(const rehr_wgrad_desc* dp) {
   if (!d.dst) d.dst = reinterpret_cast<float*>(16);
   const int rc = plan_bf16(d, p);
   if (rc != REHR_OK) return rc;
+  BrickBf16 bo;
+  WGParams pb = p;
+  if (!(d.flags & REHR_WGRAD_DIRECT) && wgrad_brick_bf16_plan(d, pb, bo))
+    return (int64_t)pb.splits * pb.T * pb.Capad * pb.Cgpad * (int64_t)sizeof(float);
   return (int64_t)p.splits * p.T * p.Capad * p.Cgpad * (int64_t)sizeof(float);
 }
 
@@ -602,16 +606,23 @@ extern "C" int rehr_wgrad_bf16(const rehr_wgrad_desc* dp, void* stream) {
   WGParams p;
   int rc = plan_bf16(*dp, p);
   if (rc != REHR_OK) return rc;
+  BrickBf16 bo;
+  // unit-stride 3x3(x3) taps: both operands as LDS bricks (REHR_WGRAD_DIRECT keeps the per-tap slab kernel)
+  const bool brick = !(dp->flags & REHR_WGRAD_DIRECT) && wgrad_brick_bf16_plan(*dp, p, bo);
   const rehr_wgrad_desc& d = p.d;
   if (!d.workspace || d.workspace_bytes < (int64_t)p.splits * p.T * p.Capad * p.Cgpad * (int64_t)sizeof(float))
     return REHR_EINVAL;
   if (p.splits > 65535) return REHR_EINVAL;
   p.slab_bias = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int t = p.Capad / p.a_tiles;
-  if (t == 128) rc = launch_wg_bf16<128, 2, 2, 64>(p, st);
-  else if (t == 64) rc = launch_wg_bf16<64, 1, 1, 64>(p, st);
-  else rc = launch_wg_bf16<32, 1, 1, 64>(p, st);
+  if (brick) {
+    rc = wgrad_brick_bf16_launch(p, bo, st);
+  } else {
+    const int t = p.Capad / p.a_tiles;
+    if (t == 128) rc = launch_wg_bf16<128, 2, 2, 64>(p, st);
+    else if (t == 64) rc = launch_wg_bf16<64, 1, 1, 64>(p, st);
+    else rc = launch_wg_bf16<32, 1, 1, 64>(p, st);
+  }
   if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
   int blocks = (int)((total + 255) / 256);

@@ -27,6 +27,14 @@ struct BrickPlanOut {
   size_t smem;
 };
 
+// brick plan of the mixed-precision weight gradient (wgrad_brick_bf16.hip)
+struct BrickBf16 {
+  int mind, minh, minw;      // halo origin relative to the lattice brick origin
+  int nb_d, nb_h, nb_w, tiles_per_img, ntiles, tiles_per_block;
+};
+bool wgrad_brick_bf16_plan(const rehr_wgrad_desc& d, WGParams& w, BrickBf16& out);
+int wgrad_brick_bf16_launch(const WGParams& w, const BrickBf16& o, hipStream_t stream);
+
 bool wgrad_brick_plan(const rehr_wgrad_desc& d, WGParams& w, BrickPlanOut& out);
 int wgrad_brick_launch(const WGParams& w, const BrickPlanOut& o, hipStream_t stream);
 

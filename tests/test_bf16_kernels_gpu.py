@@ -176,3 +176,40 @@ def test_halo_brick_kernel_virtual_concat_and_transposed_phase_taps():
     yt, _ = ops.conv_forward(xt, None, wt, None, ct, ops.ACT_NONE, 0.0, 0)
     rt = F.conv_transpose3d(xt.double(), wt.to(BF).double(), None, (1, 2, 2), (1, 1, 1))
     assert relmax(yt, rt) < 1e-2
+
+
+BRICK_WG_CASES = [  # shapes the LDS-brick weight-gradient kernel takes: (N, Cin, Cout, D, H, W, kernel, pad)
+    (1, 32, 32, 8, 16, 32, (3, 3, 3), (1, 1, 1)),
+    (2, 64, 32, 4, 16, 32, (3, 3, 3), (1, 1, 1)),      # two channel-tile pairs
+    (1, 32, 32, 8, 16, 32, (1, 3, 3), (0, 1, 1)),      # 9 taps
+    (1, 48, 96, 6, 16, 16, (3, 3, 3), (1, 1, 1)),      # masked channel tiles, padded bricks along depth
+    (2, 128, 128, 4, 8, 16, (3, 3, 3), (1, 1, 1)),     # 16 tile pairs
+]
+
+
+@pytest.mark.parametrize("case", BRICK_WG_CASES)
+def test_brick_weight_gradient_bf16_matches_slab_kernel_and_torch(case):
+    from rehrseg_amd import hip_backend
+    N, Cin, Cout, D, H, W, K, p = case
+    g = torch.Generator().manual_seed(sum(case[:6]) + 5)
+    x = act((N, Cin, D, H, W), g)
+    dz = act((N, Cout, D, H, W), g)
+    w = (torch.randn((Cout, Cin) + K, generator=g) * 0.05).to(DEV)
+    cfg = ops.ConvCfg((1, 1, 1), p)
+    wr = w.double().requires_grad_()
+    F.conv3d(x.double(), wr, None, 1, p).backward(dz.double())
+    res = {}
+    for brick in (True, False):
+        hip_backend.USE_WINOGRAD_WGRAD = brick      # False -> REHR_WGRAD_DIRECT: the per-tap slab kernel
+        try:
+            dw, _ = ops.conv_wgrad(dz, x, None, w, cfg, False)
+        finally:
+            hip_backend.USE_WINOGRAD_WGRAD = True
+        res[brick] = dw
+        assert relmax(dw, wr.grad) < 1e-4, brick
+    assert relmax(res[True], res[False]) < 1e-5
+    # virtual concat: two source tensors, one destination
+    if Cin % 64 == 0:
+        x1, x2 = x[:, :Cin // 2].contiguous(memory_format=torch.channels_last_3d), x[:, Cin // 2:].contiguous(memory_format=torch.channels_last_3d)
+        dw2, _ = ops.conv_wgrad(dz, x1, x2, w, cfg, False)
+        assert relmax(dw2, wr.grad) < 1e-4

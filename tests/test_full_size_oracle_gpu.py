@@ -12,7 +12,10 @@ the oracle's own fp32 and fp64 gradients for that tensor -- the legitimate condi
 reference's fp32 CPU run itself is only defined to 2e-3 (deep, cancelling gradients at random initialisation),
 no fp32 implementation can be closer to it than that.  The full table is printed and written to
 gpurun_out/parity_<cfg>.json; DESIGN.md section 5 quotes it.
-One oracle step takes ~25 s (fp32) / ~60 s (fp64) on the GPU box's host cores.
+One oracle step takes ~30 s in fp32; the fp64 legs take 110 s (cfg-2) and 350 s (cfg-3, one sample at a time) on the GPU
+box's 128 host threads, so by default the yardstick is read from tests/golden/conditioning_cfg{2,3}.json -- the
+fp32-vs-fp64 distances this very test measured there (same deterministic inputs and weights; REHR_PARITY_FP64=1
+recomputes them live and is how the fixtures and profiles/r02_parity_cfg*.json were produced).
 """
 import json
 import os
@@ -24,6 +27,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIVE_FP64 = os.environ.get("REHR_PARITY_FP64", "0") == "1"
+
+
+def _dtypes():
+    return (torch.float32, torch.float64) if LIVE_FP64 else (torch.float32,)
+
+
+def _conditioning(tag):
+    return json.load(open(os.path.join(ROOT, "tests", "golden", f"conditioning_{tag}.json")))
 
 
 class heartbeat:
@@ -54,7 +66,8 @@ def _l2rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
 
 
-def _gradient_table(hip_grads, g32, g64, skip=()):
+def _gradient_table(hip_grads, g32, g64, skip=(), cond=None):
+    """g64: the oracle's fp64 gradients (live run) or None, in which case `cond` holds the recorded distances."""
     rows, bad = [], []
     for k, ref in g32.items():
         if k in skip or ref is None:
@@ -63,8 +76,11 @@ def _gradient_table(hip_grads, g32, g64, skip=()):
         if n == 0.0:
             continue
         d_hip = _l2rel(hip_grads[k].cpu(), ref)
-        d_cond = _l2rel(ref, g64[k])              # the reference path's own fp32 rounding distance
-        d_hip64 = _l2rel(hip_grads[k].cpu(), g64[k])
+        if g64 is not None:
+            d_cond = _l2rel(ref, g64[k])          # the reference path's own fp32 rounding distance
+            d_hip64 = _l2rel(hip_grads[k].cpu(), g64[k])
+        else:
+            d_cond, d_hip64 = float(cond[k]), None
         rows.append({"param": k, "hip_vs_cpu_fp32": d_hip, "cpu_fp32_vs_fp64": d_cond, "hip_vs_cpu_fp64": d_hip64})
         if d_hip > 1e-3 and d_hip > 3.0 * d_cond:
             bad.append(rows[-1])
@@ -76,12 +92,13 @@ def _report(tag, summary, rows):
     worst = max(rows, key=lambda r: r["hip_vs_cpu_fp32"])
     summary.update(n_gradients=len(rows), n_over_1e3=len(over), worst=worst,
                    median_hip_vs_cpu_fp32=sorted(r["hip_vs_cpu_fp32"] for r in rows)[len(rows) // 2],
-                   max_hip_vs_cpu_fp64=max(r["hip_vs_cpu_fp64"] for r in rows),
+                   max_hip_vs_cpu_fp64=(max(r["hip_vs_cpu_fp64"] for r in rows) if rows[0]["hip_vs_cpu_fp64"] is not None else None),
                    max_cpu_fp32_vs_fp64=max(r["cpu_fp32_vs_fp64"] for r in rows))
     print(f"[{tag}] " + json.dumps(summary))
     for r in sorted(rows, key=lambda r: -r["hip_vs_cpu_fp32"])[:12]:
+        h64 = "recorded" if r["hip_vs_cpu_fp64"] is None else f"{r['hip_vs_cpu_fp64']:.2e}"
         print(f"[{tag}]   {r['param']:55s} hip-vs-cpu32 {r['hip_vs_cpu_fp32']:.2e}   cpu32-vs-cpu64 "
-              f"{r['cpu_fp32_vs_fp64']:.2e}   hip-vs-cpu64 {r['hip_vs_cpu_fp64']:.2e}")
+              f"{r['cpu_fp32_vs_fp64']:.2e}   hip-vs-cpu64 {h64}")
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, f"parity_{tag}.json"), "w") as f:
@@ -107,7 +124,7 @@ def test_cfg2_flavr_128cube_against_cpu_reference_path():
     hip = {k: p.grad.detach() for k, p in m.named_parameters() if p.grad is not None}
 
     runs = {}
-    for dt in (torch.float32, torch.float64):
+    for dt in _dtypes():
         with heartbeat("cfg2"):
             t0 = time.time()
             osd = {k: v.detach().clone().to(dt).requires_grad_() for k, v in sd.items()}
@@ -119,11 +136,16 @@ def test_cfg2_flavr_128cube_against_cpu_reference_path():
             print(f"[cfg2] oracle {dt} step: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
     r32, l32, g32, x32 = runs[torch.float32]
     fwd = float((out.detach().cpu() - r32).abs().max() / r32.abs().max())
-    rows, bad = _gradient_table(hip, g32, runs[torch.float64][2])
-    _report("cfg2", {"fwd_max_rel": fwd, "loss_hip": float(loss), "loss_cpu_fp32": l32,
-                     "loss_cpu_fp64": runs[torch.float64][1],
-                     "fwd_cpu_fp32_vs_fp64": float((r32.double() - runs[torch.float64][0]).abs().max() /
-                                                   runs[torch.float64][0].abs().max())}, rows)
+    if LIVE_FP64:
+        rows, bad = _gradient_table(hip, g32, runs[torch.float64][2])
+        extra = {"loss_cpu_fp64": runs[torch.float64][1], "yardstick": "live fp64 run",
+                 "fwd_cpu_fp32_vs_fp64": float((r32.double() - runs[torch.float64][0]).abs().max() /
+                                               runs[torch.float64][0].abs().max())}
+    else:
+        cj = _conditioning("cfg2")
+        rows, bad = _gradient_table(hip, g32, None, cond=cj["cpu_fp32_vs_fp64"])
+        extra = {"loss_cpu_fp64": cj["loss_cpu_fp64"], "yardstick": "tests/golden/conditioning_cfg2.json"}
+    _report("cfg2", dict({"fwd_max_rel": fwd, "loss_hip": float(loss), "loss_cpu_fp32": l32}, **extra), rows)
     assert fwd <= 1e-3
     assert abs(float(loss) - l32) <= 1e-4 * abs(l32)
     assert torch.allclose(xin.cpu(), x32, atol=1e-6)   # the in-place mean subtraction of the caller's tensor (:181)
@@ -153,7 +175,7 @@ def test_cfg3_segmodel_128cube_against_cpu_reference_path():
 
     runs = {}
     N = x.shape[0]
-    for dt in (torch.float32, torch.float64):
+    for dt in _dtypes():
         with heartbeat("cfg3"):
             t0 = time.time()
             osd = {k: v.detach().clone().to(dt).requires_grad_() for k, v in sd.items() if k in so.segmodel_shapes(so.ISO_PLAN)}
@@ -189,9 +211,15 @@ def test_cfg3_segmodel_128cube_against_cpu_reference_path():
         mism[name] = [int((la != lb).sum()), la.numel()]
     # conv biases sit in front of InstanceNorm: their gradient is identically 0, what is left is rounding noise
     skip = [k for k in g32 if k.endswith("conv.bias")]
-    rows, bad = _gradient_table(hip, g32, runs[torch.float64][3], skip)
-    _report("cfg3", {"fwd_max_rel": fwd, "loss_hip": loss_val, "loss_cpu_fp32": l32,
-                     "loss_cpu_fp64": runs[torch.float64][2], "argmax_mismatches_on_near_ties": mism}, rows)
+    if LIVE_FP64:
+        rows, bad = _gradient_table(hip, g32, runs[torch.float64][3], skip)
+        extra = {"loss_cpu_fp64": runs[torch.float64][2], "yardstick": "live fp64 run"}
+    else:
+        cj = _conditioning("cfg3")
+        rows, bad = _gradient_table(hip, g32, None, skip, cond=cj["cpu_fp32_vs_fp64"])
+        extra = {"loss_cpu_fp64": cj["loss_cpu_fp64"], "yardstick": "tests/golden/conditioning_cfg3.json"}
+    _report("cfg3", dict({"fwd_max_rel": fwd, "loss_hip": loss_val, "loss_cpu_fp32": l32,
+                          "argmax_mismatches_on_near_ties": mism}, **extra), rows)
     assert fwd <= 1e-3
     assert abs(loss_val - l32) <= 1e-4 * abs(l32)
     assert not bad, bad

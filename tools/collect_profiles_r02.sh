@@ -1,0 +1,30 @@
+# Round-2 evidence: per-kernel time (rocprofv3 --kernel-trace --stats), HBM traffic (FETCH_SIZE / WRITE_SIZE in separate
+# passes) and matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES) for the headline and secondary workloads.
+# Run from the repo root on the GPU box: bash tools/collect_profiles_r02.sh [part]   (part in: stats pmc stream; default all)
+R=$PWD; O=$R/gpurun_out/r2p; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+PART=${1:-all}
+B="--no-cpu-baseline"
+prof() { timeout -k 10 300 rocprofv3 "$@"; }
+if [ "$PART" = all ] || [ "$PART" = stats ]; then
+for w in flavr seg cfg4 flavr_ref; do
+  prof --kernel-trace --stats --output-format csv -d $O/k_$w -o k -- python3 $R/bench.py --workload $w --steps 5 --warmup 2 $B > $O/k_$w.log 2>&1 || exit 1
+done
+prof --kernel-trace --stats --output-format csv -d $O/k_seg_bf16 -o k -- python3 $R/bench.py --workload seg --precision bf16 --steps 5 --warmup 2 $B > $O/k_seg_bf16.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_cfg5 -o k -- python3 $R/bench.py --workload cfg5 --steps 5 --warmup 2 $B > $O/k_cfg5.log 2>&1 || exit 1
+fi
+if [ "$PART" = all ] || [ "$PART" = pmc ]; then
+for w in flavr seg; do
+  prof --kernel-trace --output-format csv -d $O/t_$w -o t -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/t_$w.log 2>&1 || exit 1
+  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f_$w -o f -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/f_$w.log 2>&1 || exit 1
+  prof --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w_$w -o w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/w_$w.log 2>&1 || exit 1
+  prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_$w -o m -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_$w.log 2>&1 || exit 1
+done
+prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_cfg5 -o m -- python3 $R/bench.py --workload cfg5 --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_cfg5.log 2>&1 || exit 1
+fi
+if [ "$PART" = all ] || [ "$PART" = stream ]; then
+prof --kernel-trace --output-format csv -d $O/t_stream -o t -- python3 $R/tools/bench_stream.py --json $O/stream_algo.json > $O/t_stream.log 2>&1 || exit 1
+prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f_stream -o f -- python3 $R/tools/bench_stream.py > $O/f_stream.log 2>&1 || exit 1
+prof --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w_stream -o w -- python3 $R/tools/bench_stream.py > $O/w_stream.log 2>&1 || exit 1
+fi
+cd $R
+ls $O
