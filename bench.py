@@ -327,14 +327,13 @@ def main():
             r["kernel"] = names.get(dominant, dominant)
             # HBM bytes per launch from the committed PMC passes of the same command (tools/pmc_traffic.py; rocprofv3
             # counters cannot be collected from inside the timed run)
-            for tp in ("r02_pmc_hbm.json", "r01_pmc_traffic.json"):
-                tp = os.path.join(ROOT, "profiles", tp)
-                if args.workload == "flavr" and size == 128 and dominant == "wino_conv" and os.path.exists(tp):
-                    k = json.load(open(tp)).get("kernels", {}).get("wino_conv_big", {})
-                    if k.get("hbm_bytes_per_launch"):
-                        r["traffic"] = k["hbm_bytes_per_launch"]
-                        r["traffic_source"] = "profiles/" + os.path.basename(tp)
-                        break
+            # (profiles/r02_pmc_hbm_flavr.json: tools/pmc_hbm.py over three rocprofv3 passes of `bench.py --workload flavr`)
+            tp = os.path.join(ROOT, "profiles", "r02_pmc_hbm_flavr.json")
+            if args.workload == "flavr" and size == 128 and dominant == "wino_conv" and os.path.exists(tp):
+                k = json.load(open(tp)).get("kernels", {}).get("wino_conv_big_kernel", {})
+                if k.get("hbm_bytes_per_launch"):
+                    r["traffic"] = k["hbm_bytes_per_launch"]
+                    r["traffic_source"] = "profiles/r02_pmc_hbm_flavr.json (PMC FETCH_SIZE x2 + WRITE_SIZE per launch)"
             rec["roofline"] = r
         for n, r in fams.items():
             if r and n != dominant:

@@ -46,6 +46,19 @@ def test_train_sr_step_uncertainty():
     ref = ref + (unc - (hat[:, 0:1].detach() - hr[:, 0:1]).abs()).abs().mean()
     ref = ref + ao.bce_dice(hat[:, 1:], hr[:, 1:])
     assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    # the gradients the step's backward left behind (train_all.py:137) against the oracle composition's
+    ref.backward()
+    worst = ("", 0.0)
+    for k, prm in m.named_parameters():
+        if prm.grad is None or osd[k].grad is None:
+            continue
+        n = float(osd[k].grad.norm())
+        if n == 0.0:
+            continue
+        e = float((prm.grad.cpu() - osd[k].grad).norm()) / n
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print("train_sr step: worst gradient l2-rel vs the oracle", worst)
+    assert worst[1] <= 1e-3, worst
     assert torch.equal(m.outconv[1].weight.detach().cpu(), w_before.cpu())  # unused by the UASR head: no update
     assert not torch.equal(m.feature_fuse1.conv[0].weight.detach().cpu(), sd["feature_fuse1.conv.0.weight"])
 
@@ -83,6 +96,33 @@ def test_train_segsr_step_with_distillation():
     ref = ref + ao.robust_ce(seg_sr, lab_hr[:, 0], None) - dc.mean()
     ref = ref + ao.distiller_loss(dsd["distill.weight"], dsd["distill.bias"], skips[1], tf[1], 0.0, 1.0, 1.0)
     assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+    # ... and the optimizer step that follows (train_all.py:554-556): the same SGD on the oracle's parameters must move
+    # every tensor the same way.  delta = new - old isolates the gradient (momentum buffer = gradient on the first step).
+    dw = dsd["distill.weight"].clone().requires_grad_()
+    db = dsd["distill.bias"].clone().requires_grad_()
+    osd2 = {k: v.detach().clone().requires_grad_() for k, v in osd.items()}
+    seg_lr, seg_sr, skips = so.seg_model(osd2, img_o, PLAN, return_features=True)
+    p = torch.softmax(seg_sr, 1)[:, 1:]
+    dc = (2 * (p * oh).sum((2, 3, 4)) + 1e-5) / torch.clip(oh.sum((2, 3, 4)) + p.sum((2, 3, 4)) + 1e-5, 1e-8)
+    ref2 = ao.robust_ce(seg_lr, lab_lr[:, 0], unc) + ao.robust_ce(seg_sr, lab_hr[:, 0], None) - dc.mean() + \
+        ao.distiller_loss(dw, db, skips[1], tf[1], 0.0, 1.0, 1.0)
+    olds = {k: v.detach().clone() for k, v in osd2.items()}
+    oopt = torch.optim.SGD(list(osd2.values()) + [dw, db], lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
+    ref2.backward()
+    oopt.step()
+    new = {canonical(k): v.detach().cpu() for k, v in student.state_dict().items()}
+    worst = ("", 0.0)
+    for k, v in osd2.items():
+        if k.endswith("conv.bias"):       # zero gradient behind InstanceNorm: the update is weight decay only
+            continue
+        d_ref = v.detach() - olds[k]
+        d_hip = new[k] - ssd[k]
+        e = float((d_hip - d_ref).norm() / (d_ref.norm() + 1e-30))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    e_d = float(((dist.distill.weight.detach().cpu() - dsd["distill.weight"]) - (dw.detach() - dsd["distill.weight"])).norm() /
+                (dw.detach() - dsd["distill.weight"]).norm())
+    print("joint step: worst parameter-update l2-rel vs the oracle's SGD step", worst, "distiller", e_d)
+    assert worst[1] <= 2e-3 and e_d <= 2e-3, (worst, e_d)
 
 
 def test_teacher_stem_shared_between_windows_gpu():
