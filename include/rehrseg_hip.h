@@ -398,6 +398,15 @@ int rehr_nchw_to_nhwc_f32(const float* x, float* y, int32_t N, int32_t C,
 int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_t C,
                           int64_t S, void* stream);
 
+/* BCE-with-logits + Dice of the SR stage's segmentation channel in one pass each way: utils/seg_utils.py:786-885
+ * (BCEDiceLoss: alpha * BCEWithLogitsLoss + beta * (1 - mean_c 2 sum(p t) / clamp(sum p^2 + sum t^2, 1e-6)), p = sigmoid(x),
+ * sums per channel over batch and space; called from train_sr, train_all.py:134).  x, t dense [N][C][S] fp32;
+ * stats[C][4] double = {sum bce, sum p t, sum p^2, sum t^2} (zeroed inside); loss = alpha * sum_c bce / (N C S) +
+ * beta * (1 - mean_c dice_c) is formed by the caller; grad_out = device scalar. */
+int rehr_bce_dice_fwd_f32(const float* x, const float* t, int32_t N, int32_t C, int64_t S, double* stats, void* stream);
+int rehr_bce_dice_bwd_f32(const float* x, const float* t, int32_t N, int32_t C, int64_t S, const double* stats,
+                          float alpha, float beta, const float* grad_out, float* dx, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Mixed-precision (*_bf16) variants of the HBM-bound fused-block kernels: the SAME arguments as the *_f32 entry
  * points above with every ACTIVATION pointer (x, y, res, dy, dx, dres) addressing bf16 elements (ld* in elements,

@@ -164,6 +164,57 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// BCE-with-logits + Dice of the SR stage's segmentation channel (utils/seg_utils.py:786-885: BCEDiceLoss =
+// alpha * BCEWithLogitsLoss + beta * (1 - mean_c 2 sum(p t) / clamp(sum p^2 + sum t^2, 1e-6)), sums per channel over
+// batch and space, p = sigmoid(x)) in one pass each way.  x, t dense [N][C][S]; stats[c][4] = {sum bce, sum p t,
+// sum p^2, sum t^2} (double, accumulated with one atomic per statistic and block).
+__global__ __launch_bounds__(256) void bce_dice_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                          int C, int64_t S, double* __restrict__ stats) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* xp = x + ((int64_t)n * C + c) * S;
+  const float* tp = t + ((int64_t)n * C + c) * S;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = xp[i], y = tp[i];
+    const float e = __expf(-fabsf(v));
+    const float p = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    a0 += fmaxf(v, 0.f) - v * y + __logf(1.f + e);
+    a1 += p * y;
+    a2 += p * p;
+    a3 += y * y;
+  }
+  __shared__ float red[4][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  if (lane == 0) { red[w][0] = a0; red[w][1] = a1; red[w][2] = a2; red[w][3] = a3; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    atomicAdd(stats + c * 4 + k, (double)(red[0][k] + red[1][k] + red[2][k] + red[3][k]));
+  }
+}
+
+__global__ __launch_bounds__(256) void bce_dice_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                          int C, int64_t S, const double* __restrict__ stats, float kbce,
+                                                          float kdice, const float* __restrict__ grad_out,
+                                                          float* __restrict__ dx) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int64_t base = ((int64_t)n * C + c) * S;
+  // d(-dice_c)/dp = -(2 y den - inter * 2 p * 2) / den^2  (den unclamped), times kdice = beta / C
+  const double inter = stats[c * 4 + 1], raw = stats[c * 4 + 2] + stats[c * 4 + 3];
+  const double den = raw < 1e-6 ? 1e-6 : raw;
+  const float A = (float)(-2.0 / den) * kdice;                               // coefficient of y
+  const float B = raw >= 1e-6 ? (float)(4.0 * inter / (den * den)) * kdice : 0.f;   // coefficient of p
+  const float go = grad_out[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[base + i], y = t[base + i];
+    const float e = __expf(-fabsf(v));
+    const float p = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[base + i] = go * (kbce * (p - y) + (A * y + B * p) * p * (1.f - p));
+  }
+}
+
 int grid_for(int64_t S) {
   int64_t b = (S + 255) / 256;
   return (int)(b > 2048 ? 2048 : b);
@@ -201,6 +252,30 @@ extern "C" int rehr_seg_loss_bwd_f32(const float* logits, int32_t ld, const floa
   else if (C == 3) SL_BWD(3);
   else SL_BWD(4);
 #undef SL_BWD
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_bce_dice_fwd_f32(const float* x, const float* t, int32_t N, int32_t C, int64_t S, double* stats,
+                                     void* stream) {
+  if (!x || !t || !stats || N < 1 || N > 65535 || C < 1 || C > 65535 || S < 1) return REHR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(stats, 0, sizeof(double) * (size_t)C * 4, st) != hipSuccess) return REHR_EHIP;
+  int bx = grid_for(S);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(bce_dice_fwd_kernel, dim3(bx, C, N), dim3(256), 0, st, x, t, C, S, stats);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_bce_dice_bwd_f32(const float* x, const float* t, int32_t N, int32_t C, int64_t S, const double* stats,
+                                     float alpha, float beta, const float* grad_out, float* dx, void* stream) {
+  if (!x || !t || !stats || !grad_out || !dx || N < 1 || N > 65535 || C < 1 || C > 65535 || S < 1) return REHR_EINVAL;
+  int bx = grid_for(S);
+  if (bx > 256) bx = 256;
+  const float kbce = alpha / (float)((double)N * C * S), kdice = beta / (float)C;
+  hipLaunchKernelGGL(bce_dice_bwd_kernel, dim3(bx, C, N), dim3(256), 0, (hipStream_t)stream, x, t, C, S, stats, kbce, kdice,
+                     grad_out, dx);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

@@ -602,3 +602,21 @@ def seg_loss_bwd(logits, target, unc, stats, w_ce, w_dice, smooth, do_bg, grad_o
                                            float(w_ce), float(w_dice), float(smooth), int(do_bg), _ptr(grad_out),
                                            _ptr(dl), Cc, _stream()), "rehr_seg_loss_bwd_f32")
     return dl
+
+
+def bce_dice_fwd(x, t):
+    """x, t dense (N, C, S) float32 -> stats (C, 4) double = {sum bce, sum p t, sum p^2, sum t^2}."""
+    _chk_dev(x, t)
+    N, Cc, S = x.shape
+    stats = torch.empty((Cc, 4), dtype=torch.float64, device=x.device)
+    L.check(L.load().rehr_bce_dice_fwd_f32(_ptr(x), _ptr(t), N, Cc, S, _ptr(stats), _stream()), "rehr_bce_dice_fwd_f32")
+    return stats
+
+
+def bce_dice_bwd(x, t, stats, alpha, beta, grad_out):
+    _chk_dev(x, t, grad_out, f64=(stats,))
+    N, Cc, S = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.load().rehr_bce_dice_bwd_f32(_ptr(x), _ptr(t), N, Cc, S, _ptr(stats), float(alpha), float(beta), _ptr(grad_out),
+                                           _ptr(dx), _stream()), "rehr_bce_dice_bwd_f32")
+    return dx

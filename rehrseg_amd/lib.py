@@ -128,6 +128,8 @@ PROTOTYPES = {
     "rehr_seg_loss_fwd_f32": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "rehr_seg_loss_bwd_f32": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _f32, _f32, _f32, _i32, _vp,
                                         _vp, _i32, _vp]),
+    "rehr_bce_dice_fwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp, _vp]),
+    "rehr_bce_dice_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp, _f32, _f32, _vp, _vp, _vp]),
     "rehr_act_fwd_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "rehr_act_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "rehr_channel_sum_f32": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp]),

@@ -208,8 +208,33 @@ class DiceLoss(nn.Module):
         return 1.0 - torch.mean(compute_per_channel_dice(self.normalization(input), target, weight=self.weight))
 
 
+class _FusedBCEDice(torch.autograd.Function):
+    """BCE-with-logits + sigmoid Dice as one HIP pass over the logits each way (rehr_bce_dice_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, alpha, beta):
+        from .. import hip_backend as hb
+        N, C = logits.shape[:2]
+        x = logits.reshape(N, C, -1).to(torch.float32).contiguous()
+        t = target.reshape(N, C, -1).to(torch.float32).contiguous()
+        stats = hb.bce_dice_fwd(x, t)
+        dice = 2 * stats[:, 1] / (stats[:, 2] + stats[:, 3]).clamp(min=1e-6)
+        loss = alpha * stats[:, 0].sum() / x.numel() + beta * (1.0 - dice.mean())
+        ctx.save_for_backward(x, t, stats)
+        ctx.cfg = (alpha, beta, tuple(logits.shape))
+        return loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .. import hip_backend as hb
+        x, t, stats = ctx.saved_tensors
+        alpha, beta, shape = ctx.cfg
+        go = grad_out.to(torch.float32).reshape(1).contiguous()
+        return hb.bce_dice_bwd(x, t, stats, alpha, beta, go).reshape(shape), None, None, None
+
+
 class BCEDiceLoss(nn.Module):
-    """alpha * BCEWithLogits + beta * Dice (ref :872-885)."""
+    """alpha * BCEWithLogits + beta * Dice (ref :872-885).  Device tensors take one fused HIP pass each way."""
 
     def __init__(self, alpha, beta):
         super().__init__()
@@ -218,6 +243,8 @@ class BCEDiceLoss(nn.Module):
         self.dice = DiceLoss()
 
     def forward(self, input, target):
+        if input.is_cuda and input.dim() >= 3 and input.shape == target.shape and self.dice.weight is None:
+            return _FusedBCEDice.apply(input, target, float(self.alpha), float(self.beta))
         return self.alpha * self.bce(input, target) + self.beta * self.dice(input, target)
 
 

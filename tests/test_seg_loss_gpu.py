@@ -55,3 +55,30 @@ def test_fused_loss_full_size_properties():
     assert float(logits.grad.sum(1).abs().max()) <= 1e-9
     val2 = mod((logits.detach() + 7.5), target)
     assert abs(float(val2) - float(val.detach())) <= 1e-5
+
+
+def test_fused_bce_dice_against_reference_fixture_and_composition():
+    """BCEDiceLoss on the device (rehr_bce_dice_{fwd,bwd}_f32) against the value / gradient the REFERENCE's BCEDiceLoss
+    produced (tests/golden/aux_losses_teacher.npz, tools/gen_golden_losses.py) and, on a two-channel batch with a
+    non-contiguous logits slice, against the torch composition in fp64."""
+    import os
+    import numpy as np
+    from oracle.detinit import det_input
+    dev = torch.device("cuda:0")
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "aux_losses_teacher.npz"))
+    x = det_input("bcedice.x", (2, 1, 4, 16, 16)).to(dev).requires_grad_()
+    t = det_input("bcedice.t", (2, 1, 4, 16, 16), "randint2").to(dev)
+    l = su.BCEDiceLoss(1.0, 1.0)(x, t)
+    l.backward()
+    assert abs(float(l.detach()) - float(G["bcedice_loss"])) < 1e-6
+    assert float((x.grad.cpu() - torch.from_numpy(G["bcedice_grad"])).abs().max()) <= 1e-4 * float(np.abs(G["bcedice_grad"]).max())
+    g = torch.Generator().manual_seed(3)
+    full = (torch.randn(3, 4, 4, 24, 20, generator=g) * 2).to(dev).requires_grad_()
+    tgt = torch.randint(0, 2, (3, 2, 4, 24, 20), generator=g).float().to(dev)
+    val = su.BCEDiceLoss(0.7, 1.3)(full[:, 1:3], tgt)          # a channel slice, like hat[:, 1:] in train_sr
+    (val * 2.0).backward()
+    ref_in = full.detach().double().cpu().requires_grad_()
+    ref = su.BCEDiceLoss(0.7, 1.3).double()(ref_in[:, 1:3], tgt.double().cpu())
+    (ref * 2.0).backward()
+    assert abs(float(val.detach()) - float(ref.detach())) <= 1e-6 * abs(float(ref.detach()))
+    assert float((full.grad.double().cpu() - ref_in.grad).abs().max()) <= 1e-5 * float(ref_in.grad.abs().max())
