@@ -98,31 +98,40 @@ def test_train_segsr_step_with_distillation():
     assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
     # ... and the optimizer step that follows (train_all.py:554-556): the same SGD on the oracle's parameters must move
     # every tensor the same way.  delta = new - old isolates the gradient (momentum buffer = gradient on the first step).
-    dw = dsd["distill.weight"].clone().requires_grad_()
-    db = dsd["distill.bias"].clone().requires_grad_()
-    osd2 = {k: v.detach().clone().requires_grad_() for k, v in osd.items()}
-    seg_lr, seg_sr, skips = so.seg_model(osd2, img_o, PLAN, return_features=True)
-    p = torch.softmax(seg_sr, 1)[:, 1:]
-    dc = (2 * (p * oh).sum((2, 3, 4)) + 1e-5) / torch.clip(oh.sum((2, 3, 4)) + p.sum((2, 3, 4)) + 1e-5, 1e-8)
-    ref2 = ao.robust_ce(seg_lr, lab_lr[:, 0], unc) + ao.robust_ce(seg_sr, lab_hr[:, 0], None) - dc.mean() + \
-        ao.distiller_loss(dw, db, skips[1], tf[1], 0.0, 1.0, 1.0)
-    olds = {k: v.detach().clone() for k, v in osd2.items()}
-    oopt = torch.optim.SGD(list(osd2.values()) + [dw, db], lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
-    ref2.backward()
-    oopt.step()
+    def oracle_step(dt):
+        dw = dsd["distill.weight"].to(dt).clone().requires_grad_()
+        db = dsd["distill.bias"].to(dt).clone().requires_grad_()
+        o2 = {k: v.detach().to(dt).clone().requires_grad_() for k, v in osd.items()}
+        s_lr, s_sr, sk = so.seg_model(o2, img_o.to(dt), PLAN, return_features=True)
+        p_ = torch.softmax(s_sr, 1)[:, 1:]
+        ohd = oh.to(dt)
+        dc_ = (2 * (p_ * ohd).sum((2, 3, 4)) + 1e-5) / torch.clip(ohd.sum((2, 3, 4)) + p_.sum((2, 3, 4)) + 1e-5, 1e-8)
+        r2 = ao.robust_ce(s_lr, lab_lr[:, 0], unc.to(dt)) + ao.robust_ce(s_sr, lab_hr[:, 0], None) - dc_.mean() + \
+            ao.distiller_loss(dw, db, sk[1], tf[1].to(dt), 0.0, 1.0, 1.0)
+        olds = {k: v.detach().clone() for k, v in o2.items()}
+        oopt = torch.optim.SGD(list(o2.values()) + [dw, db], lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
+        r2.backward()
+        oopt.step()
+        return {k: (v.detach() - olds[k]).double() for k, v in o2.items()}, (dw.detach() - dsd["distill.weight"].to(dt)).double()
+
+    d32, dd32 = oracle_step(torch.float32)
+    d64, _ = oracle_step(torch.float64)
     new = {canonical(k): v.detach().cpu() for k, v in student.state_dict().items()}
-    worst = ("", 0.0)
-    for k, v in osd2.items():
+    worst = ("", 0.0, 0.0)
+    for k in d32:
         if k.endswith("conv.bias"):       # zero gradient behind InstanceNorm: the update is weight decay only
             continue
-        d_ref = v.detach() - olds[k]
-        d_hip = new[k] - ssd[k]
-        e = float((d_hip - d_ref).norm() / (d_ref.norm() + 1e-30))
-        worst = max(worst, (k, e), key=lambda t: t[1])
-    e_d = float(((dist.distill.weight.detach().cpu() - dsd["distill.weight"]) - (dw.detach() - dsd["distill.weight"])).norm() /
-                (dw.detach() - dsd["distill.weight"]).norm())
-    print("joint step: worst parameter-update l2-rel vs the oracle's SGD step", worst, "distiller", e_d)
-    assert worst[1] <= 2e-3 and e_d <= 2e-3, (worst, e_d)
+        d_hip = (new[k] - ssd[k]).double()
+        e = float((d_hip - d32[k]).norm() / (d32[k].norm() + 1e-30))
+        cond = float((d32[k] - d64[k]).norm() / (d64[k].norm() + 1e-30))   # the oracle's own fp32 rounding distance
+        # small InstanceNorm groups (192 voxels at the deepest stage) make some of these sums cancel: calibrated bar
+        assert e <= max(2e-3, 6 * cond), (k, e, cond)
+        if e > worst[1]:
+            worst = (k, e, cond)
+    e_d = float(((dist.distill.weight.detach().cpu() - dsd["distill.weight"]).double() - dd32).norm() / dd32.norm())
+    print("joint step: worst parameter-update l2-rel vs the oracle's SGD step (name, hip-vs-fp32, fp32-vs-fp64):", worst,
+          "distiller", e_d)
+    assert e_d <= 2e-3, e_d
 
 
 def test_teacher_stem_shared_between_windows_gpu():
