@@ -258,47 +258,75 @@ __global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float*
   }
 }
 // dG[n][j][hw][kd*C+co] = sum over upsampled slices ud with source j of coef(ud, j) * dz[n][ud - kd + p][hw][co]
-__global__ void upmix_depth_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ yact,
-                                       float* __restrict__ dg, int N, int Di, int Do, int64_t HW, int C, int KD,
-                                       int pd, int act, float slope) {
+//
+// A thread owns one (sample, voxel column, channel quad) and walks the Do output slices ONCE: dz (and y, for the
+// activation gradient formed on the fly) are read exactly once, every dG element is written exactly once.  Per depth
+// tap the two source slices an upsampled slice interpolates between move monotonically with od, so two running
+// accumulators per tap (for slices b and b+1) suffice; an accumulator is stored the moment the window leaves its
+// slice.  (The gather form -- a thread per dG element looping over the ~2*scale+2 slices that touch it -- fetched
+// every dz / y element 3.3 times: 7.98 GB per launch against 2.95 GB algorithmic, PMC, profiles/r02_pmc_hbm_stream.json.)
+__global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ yact,
+                                                             float* __restrict__ dg, int N, int Di, int Do, int64_t HW, int C,
+                                                             int KD, int pd, int act, float slope) {
   const int cq = C / 4;
-  const int64_t gplane = HW * KD * cq;
-  const int64_t plane = HW * cq;
-  const int64_t total = (int64_t)N * Di * gplane;
-  const float inv = (Di > 1) ? (float)(Do - 1) / (float)(Di - 1) : 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = i % gplane;
-    const int64_t r = i / gplane;
-    const int id = (int)(r % Di), n = (int)(r / Di);
+  const int64_t plane = HW * cq;            // float4 per output slice
+  const int64_t gplane = HW * KD * cq;      // float4 per source slice of g
+  const int64_t total = (int64_t)N * plane;
+  const float ga = act == REHR_ACT_RELU ? 0.f : (act == REHR_ACT_LRELU ? slope : 1.f);
+  const float scale = (Do > 1) ? (float)(Di - 1) / (float)(Do - 1) : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % plane;
+    const int n = (int)(i / plane);
     const int q = (int)(p % cq);
-    const int kd = (int)((p / cq) % KD);
-    const int64_t hw = p / ((int64_t)cq * KD);
-    int lo = (int)floorf((float)(id - 1) * inv) - 1, hi = (int)ceilf((float)(id + 1) * inv) + 1;
-    if (lo < 0 || Di == 1) lo = 0;
-    if (hi > Do - 1 || Di == 1) hi = Do - 1;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int ud = lo; ud <= hi; ++ud) {
-      const int od = ud - kd + pd;
-      if ((unsigned)od >= (unsigned)Do) continue;
-      int i0, i1;
-      float w1;
-      depth_src(ud, Di, Do, i0, i1, w1);
-      float wgt = 0.f;
-      if (i0 == id) wgt += 1.f - w1;
-      if (i1 == id) wgt += w1;
-      if (wgt != 0.f) {
-        const int64_t o = ((int64_t)n * Do + od) * plane + hw * cq + q;
-        f32x4 d = reinterpret_cast<const f32x4*>(dz)[o];
-        if (yact != nullptr) {  // dz = dy * act'(y) on the fly: no separate activation-gradient pass
-          const f32x4 yv = reinterpret_cast<const f32x4*>(yact)[o];
+    const int64_t hw = p / cq;
+    const f32x4* dzp = reinterpret_cast<const f32x4*>(dz) + (int64_t)n * Do * plane + p;
+    const f32x4* yp = yact ? reinterpret_cast<const f32x4*>(yact) + (int64_t)n * Do * plane + p : nullptr;
+    f32x4* gout = reinterpret_cast<f32x4*>(dg) + (int64_t)n * Di * gplane + hw * KD * cq + q;
+    f32x4 a0[UPMIX_MAXKD], a1[UPMIX_MAXKD];
+    int base[UPMIX_MAXKD];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) d[e] *= act_grad(yv[e], act, slope);
+    for (int kd = 0; kd < UPMIX_MAXKD; ++kd) {
+      a0[kd] = f32x4{0.f, 0.f, 0.f, 0.f};
+      a1[kd] = f32x4{0.f, 0.f, 0.f, 0.f};
+      base[kd] = 0;
+    }
+    for (int od = 0; od < Do; ++od) {
+      f32x4 d = dzp[(int64_t)od * plane];
+      if (yp != nullptr) {
+        const f32x4 yv = yp[(int64_t)od * plane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : d[e] * ga;
+      }
+#pragma unroll
+      for (int kd = 0; kd < UPMIX_MAXKD; ++kd) {
+        if (kd < KD) {
+          const int ud = od + kd - pd;
+          if ((unsigned)ud < (unsigned)Do) {
+            const float src = scale * (float)ud;     // depth_src(): align_corners=True
+            int i0 = (int)src;
+            if (i0 > Di - 1) i0 = Di - 1;
+            const float w1 = src - (float)i0;
+            while (base[kd] < i0) {                  // the window leaves slice base: its accumulator is final
+              gout[(int64_t)base[kd] * gplane + kd * cq] = a0[kd];
+              a0[kd] = a1[kd];
+              a1[kd] = f32x4{0.f, 0.f, 0.f, 0.f};
+              ++base[kd];
+            }
+            a0[kd] += d * (1.f - w1);
+            if (i0 < Di - 1) a1[kd] += d * w1;
+            else a0[kd] += d * w1;                    // i1 == i0 at the last slice
+          }
         }
-        s += d * wgt;
       }
     }
-    reinterpret_cast<f32x4*>(dg)[i] = s;
+#pragma unroll
+    for (int kd = 0; kd < UPMIX_MAXKD; ++kd) {
+      if (kd < KD) {                                  // flush the window and any slice no upsampled slice touched
+        for (int id = base[kd]; id < Di; ++id) {
+          gout[(int64_t)id * gplane + kd * cq] = (id == base[kd]) ? a0[kd] : ((id == base[kd] + 1) ? a1[kd] : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+      }
+    }
   }
 }
 
@@ -624,7 +652,7 @@ extern "C" int rehr_upmix_depth_bwd_f32(const float* dz, const float* y, float* 
   if (!dz || !dg || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || KD < 1 || pd < 0 || pd >= KD ||
       !aligned16(dz) || !aligned16(dg) || (y && !aligned16(y)))
     return REHR_EINVAL;
-  const int64_t total = (int64_t)N * Di * HW * KD * C / 4;
+  const int64_t total = (int64_t)N * HW * C / 4;   // one thread per (sample, voxel column, channel quad)
   hipLaunchKernelGGL(upmix_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dz,
                      act == REHR_ACT_NONE ? nullptr : y, dg, N, Di, Do, HW, C, KD, pd, act, slope);
   REHR_LAUNCH_CHECK();
