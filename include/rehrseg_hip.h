@@ -408,6 +408,41 @@ int rehr_bce_dice_bwd_f32(const float* x, const float* t, int32_t N, int32_t C, 
                           float alpha, float beta, const float* grad_out, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Training-patch feed from HBM-resident volumes.
+ * Replaces the host-side numpy chain of utils/train_set.py:100-160 (TrainSetMultipleSegSREfficient.__getitem__),
+ * :205-224 (TrainSetMultipleSegSR.__getitem__) and :330-434 (TrainSetMultiple.__getitem__): transposition, crop,
+ * constant pad (utils/pad.py:14-21), flips, every-k-th slice, astype(float32), transpose / permute.
+ *   out[item][o0][o1][o2][o3] = ((lo[k] <= o_k < hi[k] for every k) ? src[base + sum_k o_k * stride[k]] : 0) * scale + bias
+ * `items` is a HOST array of n_items descriptors (copied into the kernel arguments, REHR_PATCH_MAX_ITEMS per launch);
+ * src / dst are device pointers; strides and base count source elements and may be negative (flips).
+ * ------------------------------------------------------------------------- */
+#define REHR_PATCH_F32 0
+#define REHR_PATCH_U8 1
+#define REHR_PATCH_MAX_ITEMS 16
+typedef struct {
+  const void* src;      /* volume (device), fp32 or uint8 elements */
+  int64_t base;         /* element offset of output index (0,0,0,0) */
+  int64_t stride[4];    /* source elements per step of each output axis */
+  int32_t lo[4], hi[4]; /* output indices outside [lo, hi) read as 0 (the constant pad) */
+} rehr_patch_item;
+typedef struct {
+  int32_t n_items;
+  int32_t dims[4];         /* output extent of one item */
+  int32_t src_dtype;       /* REHR_PATCH_F32 / REHR_PATCH_U8 */
+  float scale, bias;       /* applied after the pad (uncertainty maps: utils/train_set.py:147) */
+  float* dst;              /* [n_items][dst_item_stride], fp32 */
+  int64_t dst_item_stride; /* >= prod(dims) */
+} rehr_patch_gather_desc;
+int rehr_patch_gather(const rehr_patch_gather_desc* d, const rehr_patch_item* items, void* stream);
+
+/* 1-D weighted gather along one axis: dst[o][j][i] = sum_t w[j][t] * src[o][idx[j][t]][i] (idx < 0: term dropped).
+ * Serves the slice-profile blur (utils/train_set.py:306-318: F.conv2d with the (L,1) kernel of
+ * utils/blur_kernel_ops.py:7-18, padding="same") and the 1-D down-sampling of the LR simulation (:403-404).
+ * src [outer][n_in][inner], dst [outer][n_out][inner] dense fp32; idx / w [n_out][taps] on the device. */
+int rehr_axis_resample_f32(const float* src, float* dst, const int32_t* idx, const float* w, int64_t outer,
+                           int32_t n_in, int32_t n_out, int64_t inner, int32_t taps, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Mixed-precision (*_bf16) variants of the HBM-bound fused-block kernels: the SAME arguments as the *_f32 entry
  * points above with every ACTIVATION pointer (x, y, res, dy, dx, dres) addressing bf16 elements (ld* in elements,
  * % 8 == 0, C % 8 == 0); gates, gamma / beta, mean_rstd stay fp32, statistics and reduction buffers fp64, the

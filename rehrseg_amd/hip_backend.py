@@ -620,3 +620,79 @@ def bce_dice_bwd(x, t, stats, alpha, beta, grad_out):
     L.check(L.load().rehr_bce_dice_bwd_f32(_ptr(x), _ptr(t), N, Cc, S, _ptr(stats), float(alpha), float(beta), _ptr(grad_out),
                                            _ptr(dx), _stream()), "rehr_bce_dice_bwd_f32")
     return dx
+
+
+# ----------------------------------------------------------------------------- training-patch feed (section 8 f-4)
+def patch_gather(items, dims, scale=1.0, bias=0.0):
+    """One launch cuts len(items) patches out of device-resident volumes (rehr_patch_gather).
+
+    items: (src, base, stride[4], lo[4], hi[4]) per patch; src is a contiguous float32 / uint8 device tensor, base and
+    stride count source elements.  Returns float32 [len(items), *dims].  Every address the valid box [lo, hi) can
+    produce is checked here against the volume (the kernel trusts its descriptors)."""
+    dims = tuple(int(v) for v in dims)
+    if len(dims) != 4 or not items:
+        raise L.RehrsegHipError("patch_gather: four output axes and at least one item")
+    dt = items[0][0].dtype
+    if dt not in (torch.float32, torch.uint8):
+        raise L.RehrsegHipError(f"patch_gather: float32 or uint8 volumes, got {dt}")
+    arr = (L.PatchItem * len(items))()
+    for i, (src, base, stride, lo, hi) in enumerate(items):
+        if not src.is_cuda or not src.is_contiguous() or src.dtype != dt:
+            raise L.RehrsegHipError("patch_gather: contiguous device volumes of one dtype (no CPU fallback)")
+        lo_off = hi_off = int(base)
+        empty = False
+        for k in range(4):
+            if not (0 <= lo[k] <= hi[k] <= dims[k]):
+                raise L.RehrsegHipError(f"patch_gather: valid box {lo}..{hi} outside the patch {dims}")
+            if lo[k] == hi[k]:
+                empty = True
+                continue
+            a, b = int(stride[k]) * int(lo[k]), int(stride[k]) * (int(hi[k]) - 1)
+            lo_off += min(a, b)
+            hi_off += max(a, b)
+        if not empty and (lo_off < 0 or hi_off >= src.numel()):
+            raise L.RehrsegHipError(f"patch_gather: item {i} addresses [{lo_off}, {hi_off}] of a {src.numel()}-element volume")
+        arr[i].src = src.data_ptr()
+        arr[i].base = int(base)
+        for k in range(4):
+            arr[i].stride[k] = int(stride[k])
+            arr[i].lo[k] = int(lo[k])
+            arr[i].hi[k] = int(hi[k])
+    out = torch.empty((len(items),) + dims, device=items[0][0].device, dtype=torch.float32)
+    d = L.PatchGatherDesc()
+    d.n_items = len(items)
+    for k in range(4):
+        d.dims[k] = dims[k]
+    d.src_dtype = L.PATCH_U8 if dt == torch.uint8 else L.PATCH_F32
+    d.scale, d.bias = float(scale), float(bias)
+    d.dst = out.data_ptr()
+    d.dst_item_stride = out[0].numel()
+    L.check(L.load().rehr_patch_gather(C.byref(d), arr, _stream()), "rehr_patch_gather")
+    return out
+
+
+def axis_resample(x, axis, idx, w):
+    """y[..., j, ...] = sum_t w[j, t] * x[..., idx[j, t], ...] along `axis` (idx < 0 drops the term); x contiguous float32
+    on the device, idx int32 [n_out, taps], w float32 [n_out, taps] (device)."""
+    _chk_dev(x, w)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise L.RehrsegHipError("axis_resample: contiguous float32 input")
+    if idx.dtype != torch.int32 or idx.shape != w.shape or idx.dim() != 2 or not idx.is_cuda:
+        raise L.RehrsegHipError("axis_resample: idx int32 / w float32 tables of one [n_out, taps] shape on the device")
+    axis = axis % x.dim()
+    n_in = x.shape[axis]
+    if idx.numel() and int(idx.max()) >= n_in:
+        raise L.RehrsegHipError("axis_resample: tap index beyond the axis")
+    outer = 1
+    for s in x.shape[:axis]:
+        outer *= s
+    inner = 1
+    for s in x.shape[axis + 1:]:
+        inner *= s
+    n_out, taps = idx.shape
+    y = torch.empty(x.shape[:axis] + (n_out,) + x.shape[axis + 1:], device=x.device, dtype=torch.float32)
+    if y.numel() == 0:
+        return y
+    L.check(L.load().rehr_axis_resample_f32(_ptr(x), _ptr(y), _ptr(idx.contiguous()), _ptr(w.contiguous()), outer, n_in,
+                                            n_out, inner, taps, _stream()), "rehr_axis_resample_f32")
+    return y

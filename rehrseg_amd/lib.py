@@ -79,6 +79,18 @@ class DirectConvDesc(C.Structure):
     ]
 
 
+PATCH_F32, PATCH_U8, PATCH_MAX_ITEMS = 0, 1, 16
+
+
+class PatchItem(C.Structure):
+    _fields_ = [("src", _vp), ("base", _i64), ("stride", _i64 * 4), ("lo", _i32 * 4), ("hi", _i32 * 4)]
+
+
+class PatchGatherDesc(C.Structure):
+    _fields_ = [("n_items", _i32), ("dims", _i32 * 4), ("src_dtype", _i32), ("scale", _f32), ("bias", _f32),
+                ("dst", _vp), ("dst_item_stride", _i64)]
+
+
 _P_GG, _P_WG, _P_DC = C.POINTER(GatherGemmDesc), C.POINTER(WgradDesc), C.POINTER(DirectConvDesc)
 
 # name -> (restype, argtypes); must list every function include/rehrseg_hip.h declares
@@ -125,6 +137,8 @@ PROTOTYPES = {
     "rehr_quad_maxpool_fwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_quad_maxpool_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_window_stem_assemble_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, C.c_float, _vp]),
+    "rehr_patch_gather": (C.c_int, [C.POINTER(PatchGatherDesc), C.POINTER(PatchItem), _vp]),
+    "rehr_axis_resample_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp]),
     "rehr_seg_loss_fwd_f32": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "rehr_seg_loss_bwd_f32": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _f32, _f32, _f32, _i32, _vp,
                                         _vp, _i32, _vp]),

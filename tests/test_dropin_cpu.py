@@ -47,3 +47,22 @@ def test_integration_snippet_in_clean_interpreter(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "DROPIN_OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_reference_data_imports_resolve():
+    """train_all.py:24,28 name the data set classes and blur helpers by these paths."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from utils.train_set import TrainSetMultiple, TrainSetMultipleSegSREfficient\n"
+            "from utils.blur_kernel_ops import calc_extended_patch_size, parse_kernel\n"
+            "from utils.pad import target_pad\n"
+            "import rehrseg_amd.utils.train_set as t\n"
+            "assert TrainSetMultiple is t.TrainSetMultiple\n"
+            "k = parse_kernel(None, 'gaussian', 3.0); assert tuple(k.shape) == (1, 1, 7, 1) and abs(float(k.sum()) - 1) < 1e-6\n"
+            "print('ok')\n")
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code % os.path.join(root, "rehrseg_amd")], capture_output=True, text=True,
+                         cwd="/tmp", env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
