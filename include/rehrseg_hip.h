@@ -408,6 +408,26 @@ int rehr_bce_dice_bwd_f32(const float* x, const float* t, int32_t N, int32_t C, 
                           float alpha, float beta, const float* grad_out, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * sr_head.2 of the segmentation model -- Conv3d(16 -> 2, 5x5x5, stride 1, pad 2) on the depth-upsampled features,
+ * models/seg_model.py:199, :205 -- on the bf16 matrix cores (mixed-precision path, BASELINE.json configs[4]).
+ * Same descriptor as the rehr_conv_small_cout_* entry points with `x` addressing bf16 elements (ldx % 8 == 0),
+ * weights / bias fp32 in the torch layout, y (forward output, or dY for the gradients) fp32 NDHWC.
+ * Supported: Cin 16, Cout 2, 5x5x5, stride 1, pad 2, Wi % 32 == 0, 32 <= Wi <= 160 (rehr_conv5_thin_supported);
+ * anything else returns REHR_ENOSUP.  `workspace`: rehr_conv5_thin_workspace_bytes(d) bytes of device scratch
+ * (repacked weights; the weight-gradient partial sums).
+ * ------------------------------------------------------------------------- */
+int64_t rehr_conv5_thin_workspace_bytes(const rehr_direct_conv_desc* d);  /* < 0: REHR_E* */
+int rehr_conv5_thin_supported(const rehr_direct_conv_desc* d);
+int rehr_conv5_thin_fwd_bf16(const rehr_direct_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
+/* dx (bf16 NDHWC, lddx % 4 == 0) = input gradient of the layer from dY = d->y (fp32) */
+int rehr_conv5_thin_dgrad_bf16(const rehr_direct_conv_desc* d, void* dx, int32_t lddx, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+/* dw (2,16,5,5,5) fp32 = weight gradient from x = d->x (bf16) and dY = d->y (fp32), dbias (NULL or [2]) = column sums
+ * of dY; partial sums per block in the workspace, combined in a fixed order (bitwise reproducible). */
+int rehr_conv5_thin_wgrad_bf16(const rehr_direct_conv_desc* d, float* dw, float* dbias, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Training-patch feed from HBM-resident volumes.
  * Replaces the host-side numpy chain of utils/train_set.py:100-160 (TrainSetMultipleSegSREfficient.__getitem__),
  * :205-224 (TrainSetMultipleSegSR.__getitem__) and :330-434 (TrainSetMultiple.__getitem__): transposition, crop,
@@ -454,6 +474,12 @@ int rehr_scale_res_act_bwd_bf16(const void* dy, int32_t lddy, const void* y, int
                                 const float* gate, void* dx, int32_t lddx, void* dres, int32_t lddr,
                                 double* dgate_acc, int32_t N, int64_t S, int32_t C, int32_t act, float slope,
                                 void* stream);
+int rehr_upmix_depth_fwd_bf16(const void* g, const float* bias, void* y, int32_t N, int32_t Di, int32_t Do, int64_t HW,
+                              int32_t C, int32_t KD, int32_t pd, int32_t act, float slope, void* stream);
+int rehr_upmix_depth_bwd_bf16(const void* dz, const void* y, void* dg, int32_t N, int32_t Di, int32_t Do, int64_t HW,
+                              int32_t C, int32_t KD, int32_t pd, int32_t act, float slope, void* stream);
+int rehr_channel_sum_actgrad_bf16(const void* dy, const void* y, int32_t ld, int64_t rows, int32_t C, int32_t act,
+                                  float slope, float* out, double* scratch, void* stream);
 int rehr_add_channel_const_bf16(void* x, int32_t ldx, const float* k, int32_t N, int64_t S, int32_t C, void* stream);
 int rehr_instnorm_act_fwd_bf16(const void* x, int32_t ldx, const double* stats, const float* gamma, const float* beta,
                                void* y, int32_t ldy, float* mean_rstd, int32_t N, int64_t S, int32_t C, float eps,

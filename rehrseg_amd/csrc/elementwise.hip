@@ -206,8 +206,27 @@ __global__ void upsample_depth_bwd_kernel(const float* __restrict__ dy, float* _
 // A thread walks UPMIX_RUN consecutive output slices of one (sample, voxel, channel quad) column and keeps the two
 // source slices of every depth tap in registers: they change once per `upscale` steps, so g is read ~once.
 constexpr int UPMIX_RUN = 16, UPMIX_MAXKD = 5;
-__global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float* __restrict__ bias,
-                                       float* __restrict__ y, int N, int Di, int Do, int64_t HW, int C, int KD,
+
+// four consecutive elements as fp32 (activations may be fp32 or, on the mixed-precision path, bf16)
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+  __device__ static __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  __device__ static __forceinline__ void st(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Quad<__bf16> {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  __device__ static __forceinline__ f32x4 ld(const __bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  __device__ static __forceinline__ void st(__bf16* p, const f32x4 v) {
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+};
+template <typename TG, typename TY>
+__global__ void upmix_depth_fwd_kernel(const TG* __restrict__ g, const float* __restrict__ bias,
+                                       TY* __restrict__ y, int N, int Di, int Do, int64_t HW, int C, int KD,
                                        int pd, int act, float slope) {
   const int cq = C / 4;
   const int64_t plane = HW * cq;  // float4 of y per depth slice
@@ -222,7 +241,7 @@ __global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float*
     const int q = (int)(p % cq);
     const int64_t hw = p / cq;
     const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4* gn = reinterpret_cast<const f32x4*>(g) + (int64_t)n * Di * gplane + hw * KD * cq + q;
+    const TG* gn = g + ((int64_t)n * Di * gplane + hw * KD * cq + q) * 4;   // (gplane / cq count channel quads)
     int c0[UPMIX_MAXKD], c1[UPMIX_MAXKD];  // cached source slices per depth tap
     f32x4 v0[UPMIX_MAXKD], v1[UPMIX_MAXKD];
 #pragma unroll
@@ -240,11 +259,11 @@ __global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float*
             depth_src(ud, Di, Do, i0, i1, w1);
             if (i0 != c0[kd]) {
               if (i0 == c1[kd]) v0[kd] = v1[kd];  // the interval moved up by one slice
-              else v0[kd] = gn[(int64_t)i0 * gplane + kd * cq];
+              else v0[kd] = Quad<TG>::ld(gn + ((int64_t)i0 * gplane + kd * cq) * 4);
               c0[kd] = i0;
             }
             if (i1 != c1[kd]) {
-              v1[kd] = (i1 == i0) ? v0[kd] : gn[(int64_t)i1 * gplane + kd * cq];
+              v1[kd] = (i1 == i0) ? v0[kd] : Quad<TG>::ld(gn + ((int64_t)i1 * gplane + kd * cq) * 4);
               c1[kd] = i1;
             }
             s += v0[kd] * (1.f - w1) + v1[kd] * w1;
@@ -253,7 +272,7 @@ __global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float*
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = apply_act(s[e], act, slope);
-      reinterpret_cast<f32x4*>(y)[((int64_t)n * Do + od) * plane + p] = s;
+      Quad<TY>::st(y + (((int64_t)n * Do + od) * plane + p) * 4, s);
     }
   }
 }
@@ -265,8 +284,9 @@ __global__ void upmix_depth_fwd_kernel(const float* __restrict__ g, const float*
 // accumulators per tap (for slices b and b+1) suffice; an accumulator is stored the moment the window leaves its
 // slice.  (The gather form -- a thread per dG element looping over the ~2*scale+2 slices that touch it -- fetched
 // every dz / y element 3.3 times: 7.98 GB per launch against 2.95 GB algorithmic, PMC, profiles/r02_pmc_hbm_stream.json.)
-__global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ yact,
-                                                             float* __restrict__ dg, int N, int Di, int Do, int64_t HW, int C,
+template <typename TG, typename TY>
+__global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const TY* __restrict__ dz, const TY* __restrict__ yact,
+                                                             TG* __restrict__ dg, int N, int Di, int Do, int64_t HW, int C,
                                                              int KD, int pd, int act, float slope) {
   const int cq = C / 4;
   const int64_t plane = HW * cq;            // float4 per output slice
@@ -279,9 +299,9 @@ __global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const float* __res
     const int n = (int)(i / plane);
     const int q = (int)(p % cq);
     const int64_t hw = p / cq;
-    const f32x4* dzp = reinterpret_cast<const f32x4*>(dz) + (int64_t)n * Do * plane + p;
-    const f32x4* yp = yact ? reinterpret_cast<const f32x4*>(yact) + (int64_t)n * Do * plane + p : nullptr;
-    f32x4* gout = reinterpret_cast<f32x4*>(dg) + (int64_t)n * Di * gplane + hw * KD * cq + q;
+    const TY* dzp = dz + ((int64_t)n * Do * plane + p) * 4;
+    const TY* yp = yact ? yact + ((int64_t)n * Do * plane + p) * 4 : nullptr;
+    TG* gout = dg + ((int64_t)n * Di * gplane + hw * KD * cq + q) * 4;
     f32x4 a0[UPMIX_MAXKD], a1[UPMIX_MAXKD];
     int base[UPMIX_MAXKD];
 #pragma unroll
@@ -291,9 +311,9 @@ __global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const float* __res
       base[kd] = 0;
     }
     for (int od = 0; od < Do; ++od) {
-      f32x4 d = dzp[(int64_t)od * plane];
+      f32x4 d = Quad<TY>::ld(dzp + (int64_t)od * plane * 4);
       if (yp != nullptr) {
-        const f32x4 yv = yp[(int64_t)od * plane];
+        const f32x4 yv = Quad<TY>::ld(yp + (int64_t)od * plane * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : d[e] * ga;
       }
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const float* __res
             if (i0 > Di - 1) i0 = Di - 1;
             const float w1 = src - (float)i0;
             while (base[kd] < i0) {                  // the window leaves slice base: its accumulator is final
-              gout[(int64_t)base[kd] * gplane + kd * cq] = a0[kd];
+              Quad<TG>::st(gout + ((int64_t)base[kd] * gplane + kd * cq) * 4, a0[kd]);
               a0[kd] = a1[kd];
               a1[kd] = f32x4{0.f, 0.f, 0.f, 0.f};
               ++base[kd];
@@ -323,7 +343,8 @@ __global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const float* __res
     for (int kd = 0; kd < UPMIX_MAXKD; ++kd) {
       if (kd < KD) {                                  // flush the window and any slice no upsampled slice touched
         for (int id = base[kd]; id < Di; ++id) {
-          gout[(int64_t)id * gplane + kd * cq] = (id == base[kd]) ? a0[kd] : ((id == base[kd] + 1) ? a1[kd] : f32x4{0.f, 0.f, 0.f, 0.f});
+          Quad<TG>::st(gout + ((int64_t)id * gplane + kd * cq) * 4,
+                       (id == base[kd]) ? a0[kd] : ((id == base[kd] + 1) ? a1[kd] : f32x4{0.f, 0.f, 0.f, 0.f}));
         }
       }
     }
@@ -490,15 +511,16 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // column sums of dy * act'(y): the bias gradient behind a fused activation without materialising dz
-__global__ void channel_sum_actgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
+template <typename T>
+__global__ void channel_sum_actgrad_kernel(const T* __restrict__ dy, const T* __restrict__ y, int ld,
                                            int64_t rows, int C, int64_t rows_per_block, int act, float slope,
                                            double* __restrict__ scratch) {
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   int64_t r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
   column_reduce<1>(r_begin, r_end, C, scratch, 1, [&](int64_t row, int c, double(&acc)[1][4]) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(dy + row * ld + c);
-    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ld + c);
+    const f32x4 v = Quad<T>::ld(dy + row * ld + c);
+    const f32x4 yv = Quad<T>::ld(y + row * ld + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] += v[e] * act_grad(yv[e], act, slope);
   });
@@ -634,29 +656,79 @@ extern "C" int rehr_upsample_depth_bwd_f32(const float* dy, float* dx, int32_t N
   return REHR_OK;
 }
 
-extern "C" int rehr_upmix_depth_fwd_f32(const float* g, const float* bias, float* y, int32_t N, int32_t Di, int32_t Do,
-                                        int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
-                                        void* stream) {
+namespace {
+template <typename TG, typename TY>
+int upmix_depth_fwd_t(const TG* g, const float* bias, TY* y, int32_t N, int32_t Di, int32_t Do, int64_t HW, int32_t C,
+                      int32_t KD, int32_t pd, int32_t act, float slope, void* stream) {
   if (!g || !y || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || KD < 1 || pd < 0 || pd >= KD ||
       !aligned16(g) || !aligned16(y) || (bias && !aligned16(bias)) || KD > UPMIX_MAXKD)
     return REHR_EINVAL;
   const int64_t total = (int64_t)N * ((Do + UPMIX_RUN - 1) / UPMIX_RUN) * HW * C / 4;
-  hipLaunchKernelGGL(upmix_depth_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g, bias, y, N, Di, Do,
-                     HW, C, KD, pd, act, slope);
+  hipLaunchKernelGGL((upmix_depth_fwd_kernel<TG, TY>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g, bias, y, N, Di,
+                     Do, HW, C, KD, pd, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
-extern "C" int rehr_upmix_depth_bwd_f32(const float* dz, const float* y, float* dg, int32_t N, int32_t Di, int32_t Do,
-                                        int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
-                                        void* stream) {
+template <typename TG, typename TY>
+int upmix_depth_bwd_t(const TY* dz, const TY* y, TG* dg, int32_t N, int32_t Di, int32_t Do, int64_t HW, int32_t C,
+                      int32_t KD, int32_t pd, int32_t act, float slope, void* stream) {
   if (!dz || !dg || N < 1 || Di < 1 || Do < 1 || HW < 1 || C < 4 || C % 4 || KD < 1 || pd < 0 || pd >= KD ||
       !aligned16(dz) || !aligned16(dg) || (y && !aligned16(y)))
     return REHR_EINVAL;
   const int64_t total = (int64_t)N * HW * C / 4;   // one thread per (sample, voxel column, channel quad)
-  hipLaunchKernelGGL(upmix_depth_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dz,
+  hipLaunchKernelGGL((upmix_depth_bwd_kernel<TG, TY>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dz,
                      act == REHR_ACT_NONE ? nullptr : y, dg, N, Di, Do, HW, C, KD, pd, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
+}
+template <typename T>
+int channel_sum_actgrad_t(const T* dy, const T* y, int32_t ld, int64_t rows, int32_t C, int32_t act, float slope,
+                          float* out, double* scratch, void* stream) {
+  if (!dy || !y || !out || !scratch || rows < 1 || C < 4 || C % 4 || C > 1024 || ld % 4 || !aligned16(dy) ||
+      !aligned16(y))
+    return REHR_EINVAL;
+  if (hipMemsetAsync(scratch, 0, sizeof(double) * C, ST) != hipSuccess) return REHR_EHIP;
+  const int64_t rpb = rows_per_block_for(rows, C, 1);
+  const int blocks = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(channel_sum_actgrad_kernel<T>, dim3(blocks), dim3(EW_THREADS), 0, ST, dy, y, ld, rows, C, rpb, act,
+                     slope, scratch);
+  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, scratch, out, C, 0);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+}  // namespace
+
+extern "C" int rehr_channel_sum_actgrad_f32(const float* dy, const float* y, int32_t ld, int64_t rows, int32_t C,
+                                            int32_t act, float slope, float* out, double* scratch, void* stream) {
+  return channel_sum_actgrad_t<float>(dy, y, ld, rows, C, act, slope, out, scratch, stream);
+}
+extern "C" int rehr_channel_sum_actgrad_bf16(const void* dy, const void* y, int32_t ld, int64_t rows, int32_t C,
+                                             int32_t act, float slope, float* out, double* scratch, void* stream) {
+  return channel_sum_actgrad_t<__bf16>(reinterpret_cast<const __bf16*>(dy), reinterpret_cast<const __bf16*>(y), ld, rows,
+                                       C, act, slope, out, scratch, stream);
+}
+extern "C" int rehr_upmix_depth_fwd_f32(const float* g, const float* bias, float* y, int32_t N, int32_t Di, int32_t Do,
+                                        int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
+                                        void* stream) {
+  return upmix_depth_fwd_t<float, float>(g, bias, y, N, Di, Do, HW, C, KD, pd, act, slope, stream);
+}
+extern "C" int rehr_upmix_depth_bwd_f32(const float* dz, const float* y, float* dg, int32_t N, int32_t Di, int32_t Do,
+                                        int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
+                                        void* stream) {
+  return upmix_depth_bwd_t<float, float>(dz, y, dg, N, Di, Do, HW, C, KD, pd, act, slope, stream);
+}
+// mixed precision: g / dg and y / dz are bf16 (8-byte quads), bias fp32, arithmetic fp32
+extern "C" int rehr_upmix_depth_fwd_bf16(const void* g, const float* bias, void* y, int32_t N, int32_t Di, int32_t Do,
+                                         int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
+                                         void* stream) {
+  return upmix_depth_fwd_t<__bf16, __bf16>(reinterpret_cast<const __bf16*>(g), bias, reinterpret_cast<__bf16*>(y), N, Di,
+                                           Do, HW, C, KD, pd, act, slope, stream);
+}
+extern "C" int rehr_upmix_depth_bwd_bf16(const void* dz, const void* y, void* dg, int32_t N, int32_t Di, int32_t Do,
+                                         int64_t HW, int32_t C, int32_t KD, int32_t pd, int32_t act, float slope,
+                                         void* stream) {
+  return upmix_depth_bwd_t<__bf16, __bf16>(reinterpret_cast<const __bf16*>(dz), reinterpret_cast<const __bf16*>(y),
+                                           reinterpret_cast<__bf16*>(dg), N, Di, Do, HW, C, KD, pd, act, slope, stream);
 }
 
 extern "C" int rehr_window_stem_assemble_f32(const float* g0, const float* g1, const float* g2, const float* mean,
@@ -722,19 +794,9 @@ extern "C" int rehr_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act
   return REHR_OK;
 }
 extern "C" int rehr_channel_sum_actgrad_f32(const float* dy, const float* y, int32_t ld, int64_t rows, int32_t C,
-                                            int32_t act, float slope, float* out, double* scratch, void* stream) {
-  if (!dy || !y || !out || !scratch || rows < 1 || C < 4 || C % 4 || C > 1024 || ld % 4 || !aligned16(dy) ||
-      !aligned16(y))
-    return REHR_EINVAL;
-  if (hipMemsetAsync(scratch, 0, sizeof(double) * C, ST) != hipSuccess) return REHR_EHIP;
-  const int64_t rpb = rows_per_block_for(rows, C, 1);
-  const int blocks = (int)((rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(channel_sum_actgrad_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST, dy, y, ld, rows, C, rpb, act,
-                     slope, scratch);
-  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, scratch, out, C, 0);
-  REHR_LAUNCH_CHECK();
-  return REHR_OK;
-}
+                                            int32_t act, float slope, float* out, double* scratch, void* stream);
+extern "C" int rehr_channel_sum_actgrad_bf16(const void* dy, const void* y, int32_t ld, int64_t rows, int32_t C,
+                                             int32_t act, float slope, float* out, double* scratch, void* stream);
 
 extern "C" int rehr_copy_channels_f32(const float* x, int32_t ldx, float* y, int32_t ldy, int64_t rows,
                                       int32_t C, void* stream) {

@@ -479,28 +479,30 @@ def upmix_depth_fwd(g, bias, Do, Cc, KD, pd, act, slope):
     _chk_dev(g, bias)
     N, _, Di, H, W = g.shape
     y = new_act(N, Cc, Do, H, W, like=g)
-    L.check(L.load().rehr_upmix_depth_fwd_f32(_ptr(g), _ptr(bias), _ptr(y), N, Di, Do, H * W, Cc, KD, pd, act, slope,
-                                              _stream()), "rehr_upmix_depth_fwd_f32")
+    fn, name = _fn("rehr_upmix_depth_fwd", g)
+    L.check(fn(_ptr(g), _ptr(bias), _ptr(y), N, Di, Do, H * W, Cc, KD, pd, act, slope, _stream()), name)
     return y
 
 
 def upmix_depth_bwd(dy, y, Di, KD, pd, act, slope):
     """dg of upmix_depth_fwd from the output gradient dy and the saved output y (dz = dy * act'(y) on the fly)."""
     _chk_dev(dy, y)
+    _same_dtype(dy, y)
     N, Cc, Do, H, W = dy.shape
     dg = new_act(N, KD * Cc, Di, H, W, like=dy)
-    L.check(L.load().rehr_upmix_depth_bwd_f32(_ptr(dy), _ptr(y), _ptr(dg), N, Di, Do, H * W, Cc, KD, pd, act, slope,
-                                              _stream()), "rehr_upmix_depth_bwd_f32")
+    fn, name = _fn("rehr_upmix_depth_bwd", dy)
+    L.check(fn(_ptr(dy), _ptr(y), _ptr(dg), N, Di, Do, H * W, Cc, KD, pd, act, slope, _stream()), name)
     return dg
 
 
 def channel_sum_actgrad(dy, y, act, slope):
     _chk_dev(dy, y)
+    _same_dtype(dy, y)
     N, S, Cc = _nsc(dy)
     out = torch.empty((Cc,), dtype=torch.float32, device=dy.device)
     scratch = torch.empty((Cc,), dtype=torch.float64, device=dy.device)
-    L.check(L.load().rehr_channel_sum_actgrad_f32(_ptr(dy), _ptr(y), Cc, N * S, Cc, act, slope, _ptr(out), _ptr(scratch),
-                                                  _stream()), "rehr_channel_sum_actgrad_f32")
+    fn, name = _fn("rehr_channel_sum_actgrad", dy)
+    L.check(fn(_ptr(dy), _ptr(y), Cc, N * S, Cc, act, slope, _ptr(out), _ptr(scratch), _stream()), name)
     return out
 
 
@@ -696,3 +698,59 @@ def axis_resample(x, axis, idx, w):
     L.check(L.load().rehr_axis_resample_f32(_ptr(x), _ptr(y), _ptr(idx.contiguous()), _ptr(w.contiguous()), outer, n_in,
                                             n_out, inner, taps, _stream()), "rehr_axis_resample_f32")
     return y
+
+
+# ----------------------------------------------------------------------------- sr_head.2 on the bf16 matrix cores
+def _thin5_ws(d, dev):
+    n = int(L.load().rehr_conv5_thin_workspace_bytes(C.byref(d)))
+    if n < 0:
+        L.check(n, "rehr_conv5_thin_workspace_bytes")
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=dev), n
+
+
+def thin5_supported(x_shape, w_shape, pad):
+    """Conv3d(16 -> 2, 5x5x5, stride 1, pad 2) with W % 32 == 0, W <= 160: the shapes the MFMA kernels take."""
+    N, Cin, D, H, W = x_shape
+    return (tuple(w_shape) == (2, 16, 5, 5, 5) and Cin == 16 and tuple(pad) == (2, 2, 2) and W % 32 == 0
+            and 32 <= W <= 160 and D * H * W * 16 * 2 < 2 ** 32)
+
+
+def thin5_fwd(x, w, bias):
+    """y (fp32) = conv3d(x (bf16 NDHWC), w, bias) for sr_head.2 (rehr_conv5_thin_fwd_bf16)."""
+    _chk_dev(x, w, bias)
+    if x.dtype != torch.bfloat16:
+        raise L.RehrsegHipError("thin5_fwd: bf16 activations")
+    N, Cin, D, H, W = x.shape
+    y = new_act(N, 2, D, H, W, like=x, dtype=torch.float32)
+    d = _direct_desc(x, w.contiguous(), bias, y, (1, 1, 1), (2, 2, 2), 0, 0.0, None, 0)
+    ws, n = _thin5_ws(d, x.device)
+    L.check(L.load().rehr_conv5_thin_fwd_bf16(C.byref(d), _ptr(ws), n, _stream()), "rehr_conv5_thin_fwd_bf16")
+    return y
+
+
+def thin5_dgrad(dy, w):
+    """dx (bf16 NDHWC, 16 channels) of sr_head.2 from dY (fp32 NDHWC, 2 channels)."""
+    _chk_dev(dy, w)
+    if dy.dtype != torch.float32:
+        raise L.RehrsegHipError("thin5_dgrad: fp32 output gradient")
+    N, _, D, H, W = dy.shape
+    dx = new_act(N, 16, D, H, W, like=dy, dtype=torch.bfloat16)
+    d = _direct_desc(dx, w.contiguous(), None, dy, (1, 1, 1), (2, 2, 2), 0, 0.0, None, 0)
+    ws, n = _thin5_ws(d, dy.device)
+    L.check(L.load().rehr_conv5_thin_dgrad_bf16(C.byref(d), _ptr(dx), 16, _ptr(ws), n, _stream()),
+            "rehr_conv5_thin_dgrad_bf16")
+    return dx
+
+
+def thin5_wgrad(x, w, dy, want_bias=False):
+    """(dw (2,16,5,5,5), db) fp32 of sr_head.2 from x (bf16) and dY (fp32)."""
+    _chk_dev(x, w, dy)
+    if x.dtype != torch.bfloat16 or dy.dtype != torch.float32:
+        raise L.RehrsegHipError("thin5_wgrad: bf16 activations, fp32 output gradient")
+    d = _direct_desc(x, w.contiguous(), None, dy, (1, 1, 1), (2, 2, 2), 0, 0.0, None, 0)
+    ws, n = _thin5_ws(d, x.device)
+    dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+    db = torch.empty(2, dtype=torch.float32, device=x.device) if want_bias else None
+    L.check(L.load().rehr_conv5_thin_wgrad_bf16(C.byref(d), _ptr(dw), _ptr(db), _ptr(ws), n, _stream()),
+            "rehr_conv5_thin_wgrad_bf16")
+    return dw, db

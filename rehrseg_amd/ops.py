@@ -275,6 +275,10 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     if _thin_out(w, cfg, x2 is not None):
         if stats_mode:
             raise NotImplementedError("statistics epilogue on a thin-output conv")
+        if x1.dtype == torch.bfloat16:   # sr_head.2 on the matrix cores (fused_conv3d only routes supported shapes here)
+            if act != ACT_NONE:
+                raise NotImplementedError("activation behind the bf16 thin-output conv")
+            return be.thin5_fwd(x1, w, bias), None
         y = be.new_act(N, Cout, *out_dims, like=x1)
         be.small_cout_fwd(x1, w, bias, y, cfg.pad, act, slope)
         return y, None
@@ -309,13 +313,16 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     return y, stats
 
 
-def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True):
-    """Input gradient(s) of conv_forward: (dx1, dx2)."""
+def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True, x_dtype=None):
+    """Input gradient(s) of conv_forward: (dx1, dx2).  `x_dtype`: dtype of the layer's input where it differs from
+    dz's (the bf16 thin-output head takes bf16 in, fp32 out)."""
     be = get_backend()
     N = dz.shape[0]
     K = tuple(w.shape[2:])
     Cz = dz.shape[1]
     if _thin_out(w, cfg, c2 > 0):
+        if x_dtype == torch.bfloat16:
+            return (be.thin5_dgrad(dz.float() if dz.dtype != torch.float32 else dz, w) if need1 else None), None
         return (be.small_cout_dgrad(dz, w, (N, c1) + tuple(in_dims), cfg.pad) if need1 else None), None
     out = []
     for (lo, cnt, need) in ((0, c1, need1), (c1, c2, need2)):
@@ -422,6 +429,8 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
                  (kpad, 1, 0), False, db)
         return tmp[:, :kcols].reshape(w.shape).contiguous(), db
     if _thin_out(w, cfg, x2 is not None):
+        if x1.dtype == torch.bfloat16:
+            return be.thin5_wgrad(x1, w, dz.float() if dz.dtype != torch.float32 else dz, want_bias)
         return be.small_cout_wgrad(x1, w, dz, cfg.pad, want_bias)
     dw = out if out is not None else torch.empty(tuple(w.shape), dtype=w.dtype, device=w.device)
     db = None
@@ -518,7 +527,7 @@ class _FusedConv(torch.autograd.Function):
         c2 = x2.shape[1] if has_x2 else 0
         dx1 = dx2 = None
         if need[0] or (has_x2 and need[1]):
-            dx1, dx2 = conv_dgrad(dz, w, _spatial(x1), c1, c2, cfg, need[0], has_x2 and need[1])
+            dx1, dx2 = conv_dgrad(dz, w, _spatial(x1), c1, c2, cfg, need[0], has_x2 and need[1], x_dtype=x1.dtype)
         dw = db = None
         if need[2] or (has_b and need[3]):
             c1_ = x1.shape[1] + (x2.shape[1] if has_x2 else 0)
@@ -551,6 +560,9 @@ def fused_conv3d(x, w, b=None, stride=1, padding=0, *, x2=None, transposed=False
     # operand dtype: the thin layers are fp32 kernels; the matrix-core layers follow mixed_precision() / their input
     cin = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     thin = cin <= 2 or _thin_out(w, cfg, x2 is not None)
+    if thin and x.dtype == torch.bfloat16 and mode == "plain" and act == ACT_NONE and \
+            get_backend().thin5_supported(tuple(x.shape), tuple(w.shape), cfg.pad):
+        thin = False   # sr_head.2 with bf16 features: the matrix-core kernels of thin_conv_bf16.hip (fp32 result)
     want = torch.float32 if thin else (torch.bfloat16 if (_mixed or x.dtype == torch.bfloat16) else x.dtype)
     if want in (torch.float32, torch.bfloat16):
         x = x if x.dtype == want else x.to(want)
@@ -604,8 +616,7 @@ def upsample_conv3d_depth(x, w, b, scale, act=ACT_NONE, slope=0.0):
     Do = int(x.shape[2] * scale)
     wg = w.permute(2, 0, 1, 3, 4).reshape(KD * Cout, Cin, 1, KH, KW)  # row kd*Cout + co
     g = fused_conv3d(x, wg, None, 1, (0, KH // 2, KW // 2))
-    if g.dtype != torch.float32:   # mixed precision: the per-tap responses come back bf16, the HR head stays fp32
-        g = g.float()
+    # mixed precision: the per-tap responses come back bf16 and the upsampled features stay bf16 (rehr_upmix_depth_*_bf16)
     return _UpMixDepth.apply(g, b, Do, Cout, KD, KD // 2, int(act), float(slope))
 
 

@@ -213,3 +213,75 @@ def test_brick_weight_gradient_bf16_matches_slab_kernel_and_torch(case):
         x1, x2 = x[:, :Cin // 2].contiguous(memory_format=torch.channels_last_3d), x[:, Cin // 2:].contiguous(memory_format=torch.channels_last_3d)
         dw2, _ = ops.conv_wgrad(dz, x1, x2, w, cfg, False)
         assert relmax(dw2, wr.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------- sr_head.2 on the matrix cores
+THIN5_CASES = [(1, 3, 5, 32), (2, 7, 6, 64), (1, 12, 9, 96), (1, 33, 13, 128), (1, 9, 4, 160)]
+
+
+@pytest.mark.parametrize("shape", THIN5_CASES)
+def test_thin5_conv_vs_torch(shape):
+    """Conv3d(16 -> 2, 5x5x5, pad 2) forward / input gradient / weight + bias gradient of the bf16 MFMA kernels
+    (models/seg_model.py:199) against torch on the same bf16-rounded operands (fp32 arithmetic).  Products of bf16
+    values are exact in fp32, so only the summation order differs: 1e-5 of the largest value; the input gradient is
+    stored bf16 (2^-9 relative)."""
+    import torch.nn.functional as F
+    from rehrseg_amd import hip_backend as hb
+    N, D, H, W = shape
+    assert hb.thin5_supported((N, 16, D, H, W), (2, 16, 5, 5, 5), (2, 2, 2))
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn(N, 16, D, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(2, 16, 5, 5, 5, generator=g) * 0.05).to(DEV)
+    b = torch.randn(2, generator=g).to(DEV)
+    dy = torch.randn(N, 2, D, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    xb = x.to(torch.bfloat16)
+    xr, wr, dyr = xb.float(), w.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+
+    y = hb.thin5_fwd(xb, w, b)
+    ref = F.conv3d(xr, wr, b, padding=2)
+    assert y.dtype == torch.float32 and y.shape == ref.shape
+    assert (y - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+    dx = hb.thin5_dgrad(dy, w)
+    ref = torch.nn.grad.conv3d_input(xr.shape, wr, dyr, padding=2)
+    assert dx.dtype == torch.bfloat16
+    assert (dx.float() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max()
+
+    dw, db = hb.thin5_wgrad(xb, w, dy, True)
+    ref = torch.nn.grad.conv3d_weight(xr, w.shape, dyr, padding=2)
+    assert (dw - ref).abs().max() <= 2e-5 * ref.abs().max()
+    torch.testing.assert_close(db, dy.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    dw2, _ = hb.thin5_wgrad(xb, w, dy, False)
+    assert torch.equal(dw, dw2)   # fixed summation order
+
+
+def test_thin5_rejects_other_shapes():
+    from rehrseg_amd import hip_backend as hb, lib
+    assert not hb.thin5_supported((1, 16, 8, 8, 48), (2, 16, 5, 5, 5), (2, 2, 2))
+    assert not hb.thin5_supported((1, 16, 8, 8, 64), (2, 16, 3, 3, 3), (1, 1, 1))
+    x = torch.zeros(1, 16, 8, 8, 48, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    with pytest.raises(lib.RehrsegHipError):
+        hb.thin5_fwd(x, torch.zeros(2, 16, 5, 5, 5, device=DEV), None)
+
+
+def test_upmix_bf16_matches_fp32():
+    """The depth-upsample + tap-sum pass with bf16 activations both ways against the fp32 kernel on the same rounded
+    inputs (arithmetic is fp32 in both; only the stores round)."""
+    from rehrseg_amd import hip_backend as hb
+    g_ = torch.Generator(device="cpu").manual_seed(3)
+    N, Cc, KD, Di, Do, H, W = 2, 16, 3, 5, 20, 6, 8
+    g = torch.randn(N, KD * Cc, Di, H, W, generator=g_).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    bias = torch.randn(Cc, generator=g_).to(DEV)
+    gb = g.to(torch.bfloat16)
+    y32 = hb.upmix_depth_fwd(gb.float(), bias, Do, Cc, KD, 1, 1, 0.0)
+    y16 = hb.upmix_depth_fwd(gb, bias, Do, Cc, KD, 1, 1, 0.0)
+    assert y16.dtype == torch.bfloat16
+    torch.testing.assert_close(y16.float(), y32, rtol=2.0 ** -8, atol=1e-6)
+    dy = torch.randn(N, Cc, Do, H, W, generator=g_).to(DEV).contiguous(memory_format=torch.channels_last_3d).to(torch.bfloat16)
+    dg32 = hb.upmix_depth_bwd(dy.float(), y16.float(), Di, KD, 1, 1, 0.0)
+    dg16 = hb.upmix_depth_bwd(dy, y16, Di, KD, 1, 1, 0.0)
+    assert dg16.dtype == torch.bfloat16
+    torch.testing.assert_close(dg16.float(), dg32, rtol=2.0 ** -8, atol=1e-5)
+    db32 = hb.channel_sum_actgrad(dy.float(), y16.float(), 1, 0.0)
+    db16 = hb.channel_sum_actgrad(dy, y16, 1, 0.0)
+    torch.testing.assert_close(db16, db32, rtol=1e-5, atol=1e-4)
