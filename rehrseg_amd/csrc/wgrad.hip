@@ -248,26 +248,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WGParams p) {
 }
 
 // dst[a*sa + c*sc + wt*st] (+)= sum_split slab[split][tap][a][c]
-__global__ void wgrad_reduce_kernel(const WGParams p) {
+// G threads share an output element: thread (e, g) sums the slabs k = g, g + G, ... (four independent loads in flight),
+// the G partial sums are combined in a fixed order through LDS -- the result does not depend on the launch geometry of
+// anything but this kernel, i.e. it stays bitwise reproducible.  (One thread per element walking all slabs serially was a
+// latency-bound chain: 36-47 us per launch on the 32/64-channel layers, 1.2-1.6 ms of a mixed-precision step.)
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGParams p) {
+  constexpr int EPB = 256 / G;   // elements per block
+  __shared__ float part[G > 1 ? 256 : 1];
   const rehr_wgrad_desc& d = p.d;
   const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
   const int64_t slab_sz = (int64_t)p.T * p.Capad * p.Cgpad;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % d.Cg);
-    const int64_t r = i / d.Cg;
+  const int el = threadIdx.x % EPB, g = threadIdx.x / EPB;
+  for (int64_t i0 = (int64_t)blockIdx.x * EPB; i0 < total; i0 += (int64_t)gridDim.x * EPB) {
+    const int64_t i = i0 + el;
+    const bool ok = i < total;
+    const int c = ok ? (int)(i % d.Cg) : 0;
+    const int64_t r = ok ? i / d.Cg : 0;
     const int a = (int)(r % d.Ca);
     const int tap = (int)(r / d.Ca);
     const float* s = d.workspace + ((int64_t)tap * p.Capad + a) * p.Cgpad + c;
-    float sum = 0.f;
-    for (int k = 0; k < p.splits; ++k) sum += s[(int64_t)k * slab_sz];
-    const int jw = tap % d.tw.count;
-    const int jh = (tap / d.tw.count) % d.th.count;
-    const int jd = tap / (d.tw.count * d.th.count);
-    const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW +
-                   (d.tw.k0 + d.tw.ks * jw);
-    float* o = d.dst + a * d.dst_sa + c * d.dst_sc + wt * d.dst_st;
-    *o = d.accumulate ? (*o + sum) : sum;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+      int k = g;
+      for (; k + 3 * G < p.splits; k += 4 * G) {
+        s0 += s[(int64_t)k * slab_sz];
+        s1 += s[(int64_t)(k + G) * slab_sz];
+        s2 += s[(int64_t)(k + 2 * G) * slab_sz];
+        s3 += s[(int64_t)(k + 3 * G) * slab_sz];
+      }
+      for (; k < p.splits; k += G) s0 += s[(int64_t)k * slab_sz];
+    }
+    float sum = (s0 + s1) + (s2 + s3);
+    if (G > 1) {
+      __syncthreads();
+      part[threadIdx.x] = sum;
+      __syncthreads();
+      if (g == 0) {
+#pragma unroll
+        for (int q = 1; q < G; ++q) sum += part[q * EPB + el];
+      }
+    }
+    if (ok && g == 0) {
+      const int jw = tap % d.tw.count;
+      const int jh = (tap / d.tw.count) % d.th.count;
+      const int jd = tap / (d.tw.count * d.th.count);
+      const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW +
+                     (d.tw.k0 + d.tw.ks * jw);
+      float* o = d.dst + a * d.dst_sa + c * d.dst_sc + wt * d.dst_st;
+      *o = d.accumulate ? (*o + sum) : sum;
+    }
   }
   if (p.slab_bias != nullptr && d.dbias != nullptr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.Ca;
@@ -279,6 +309,20 @@ __global__ void wgrad_reduce_kernel(const WGParams p) {
   }
 }
 
+int launch_wgrad_reduce(const WGParams& p, hipStream_t st) {
+  const int64_t total = (int64_t)p.T * p.d.Ca * p.d.Cg;
+  // few elements and many slabs: spread every element over 8 threads
+  if (total < ((int64_t)1 << 19) && p.splits >= 16) {
+    int64_t blocks = (total + 31) / 32;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  } else {
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Mixed precision: bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 slabs / result.
@@ -624,10 +668,7 @@ extern "C" int rehr_wgrad_bf16(const rehr_wgrad_desc* dp, void* stream) {
     else rc = launch_wg_bf16<32, 1, 1, 64>(p, st);
   }
   if (rc != REHR_OK) return rc;
-  const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+  launch_wgrad_reduce(p, st);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -683,10 +724,7 @@ extern "C" int rehr_wgrad_f32(const rehr_wgrad_desc* dp, void* stream) {
     else rc = launch_wg<32, 1, 1, 64>(p, st);
   }
   if (rc != REHR_OK) return rc;
-  const int64_t total = (int64_t)p.T * d.Ca * d.Cg;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+  launch_wgrad_reduce(p, st);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

@@ -449,7 +449,11 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   const uint32_t ubase = (uint32_t)(r * 4) * xi_stride + (uint32_t)nt0 * nt_stride;
   auto load_u = [&](const Item& t, int kk, f32x4 (&ub)[2][4]) {
     const int chunk = t.chunk < p.kchunks ? t.chunk : 0;  // (one item past the end is requested, never used)
+#ifdef WINO_DBG_SAMEW
+    const uint32_t base = ubase + 0u * (uint32_t)(t.jd + chunk + kk);
+#else
     const uint32_t base = ubase + (uint32_t)(t.jd * 16) * xi_stride + (uint32_t)(chunk * 4 + kk) * 1024u;
+#endif
 #pragma unroll
     for (int fn = 0; fn < 2; ++fn)
 #pragma unroll
@@ -473,6 +477,9 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
   // MFMAs) into its A fragments; weights arrive one k-group (2 micro-steps) ahead.
   f32x4 ra[4], rb[4];
   auto issue_reads = [&](int buf, const int kk, const int fm) {
+#ifdef WINO_DBG_NOLDS
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LDX + kk * 8);
@@ -547,7 +554,9 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
     WINO_MICRO(1, VB, VA, u0, issue_reads(cur, 3, 0))
     WINO_MICRO(0, VA, VB, u1, (issue_reads(cur, 3, 1), load_u(ni, 0, u0)))
     // every read of slice `cur` has been consumed, every write of `nxt` was issued long ago
+#ifndef WINO_DBG_NOBAR
     __syncthreads();
+#endif
     WINO_MICRO(1, VB, VA, u1, issue_reads(nxt, 0, 0))
     ci = ni;
   }

@@ -563,7 +563,10 @@ def fused_conv3d(x, w, b=None, stride=1, padding=0, *, x2=None, transposed=False
     if thin and x.dtype == torch.bfloat16 and mode == "plain" and act == ACT_NONE and \
             get_backend().thin5_supported(tuple(x.shape), tuple(w.shape), cfg.pad):
         thin = False   # sr_head.2 with bf16 features: the matrix-core kernels of thin_conv_bf16.hip (fp32 result)
-    want = torch.float32 if thin else (torch.bfloat16 if (_mixed or x.dtype == torch.bfloat16) else x.dtype)
+    if thin:   # fp32 kernels: bf16 features are cast up, anything else (the fp64 host-logic tests) keeps its dtype
+        want = torch.float32 if x.dtype == torch.bfloat16 else x.dtype
+    else:
+        want = torch.bfloat16 if (_mixed or x.dtype == torch.bfloat16) else x.dtype
     if want in (torch.float32, torch.bfloat16):
         x = x if x.dtype == want else x.to(want)
         x2 = x2 if (x2 is None or x2.dtype == want) else x2.to(want)
