@@ -400,25 +400,49 @@ __global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(
 }
 
 // dst[co*sa + ci*sc + tap*st] (+)= sum_{r,c} G[r][a] G[c][b] sum_splits slab[s][jd][r*4+c][co][ci]
-__global__ void wino_wgrad_reduce_kernel(const WWParams p) {
+// NG threads share an output element on the layers with few channels and many slabs (thread (e, g) sums the slabs
+// g, g + NG, ...; the partial sums are combined in a fixed order through LDS): one thread per element walking all slabs
+// was a latency-bound chain there (49 us per launch on average in cfg-2).
+template <int NG>
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const WWParams p) {
+  constexpr int EPB = 256 / NG;
+  __shared__ float part[NG > 1 ? 16 * 256 : 1];
   const rehr_wgrad_desc& d = p.d;
   const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
   const int KD = d.td.count;
   const int64_t total = (int64_t)KD * d.Ca * d.Cg;
   const int64_t plane = (int64_t)p.Capad * p.Cgpad;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % d.Cg);
-    const int64_t t = i / d.Cg;
+  const int el = threadIdx.x % EPB, g = threadIdx.x / EPB;
+  for (int64_t i0 = (int64_t)blockIdx.x * EPB; i0 < total; i0 += (int64_t)gridDim.x * EPB) {
+    const int64_t i = i0 + el;
+    const bool ok = i < total;
+    const int ci = ok ? (int)(i % d.Cg) : 0;
+    const int64_t t = ok ? i / d.Cg : 0;
     const int co = (int)(t % d.Ca);
     const int jd = (int)(t / d.Ca);
     float u[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) u[x] = 0.f;
-    for (int s = 0; s < p.splits; ++s) {
-      const float* sp = p.slabs + (((int64_t)s * KD + jd) * 16) * plane + (int64_t)co * p.Cgpad + ci;
+    if (ok) {
+      for (int s = g; s < p.splits; s += NG) {
+        const float* sp = p.slabs + (((int64_t)s * KD + jd) * 16) * plane + (int64_t)co * p.Cgpad + ci;
 #pragma unroll
-      for (int x = 0; x < 16; ++x) u[x] += sp[x * plane];
+        for (int x = 0; x < 16; ++x) u[x] += sp[x * plane];
+      }
     }
+    if (NG > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int x = 0; x < 16; ++x) part[x * 256 + threadIdx.x] = u[x];
+      __syncthreads();
+      if (g == 0) {
+#pragma unroll
+        for (int q = 1; q < NG; ++q)
+#pragma unroll
+          for (int x = 0; x < 16; ++x) u[x] += part[x * 256 + q * EPB + el];
+      }
+    }
+    if (!ok || g != 0) continue;
     float tmp[3][4];  // G^T u : [a][c]
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -571,9 +595,15 @@ int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
   else rc = virt ? launch_ww<2, 1, true>(p, grid, stream) : launch_ww<2, 1, false>(p, grid, stream);
   if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)d.td.count * d.Ca * d.Cg;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  if (total < ((int64_t)1 << 17) && p.splits >= 16) {
+    int blocks = (int)((total + 31) / 32);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel<8>, dim3(blocks), dim3(256), 0, stream, p);
+  } else {
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
+  }
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
