@@ -427,6 +427,17 @@ int rehr_conv5_thin_dgrad_bf16(const rehr_direct_conv_desc* d, void* dx, int32_t
 int rehr_conv5_thin_wgrad_bf16(const rehr_direct_conv_desc* d, float* dw, float* dbias, void* workspace,
                                int64_t workspace_bytes, void* stream);
 
+/* The same layer on the fp32 matrix cores (v_mfma_f32_16x16x4_f32) for the fp32 path: x, dx fp32 (ldx, lddx % 4 == 0),
+ * Wi % 32 == 0, 32 <= Wi <= 128; same descriptor, same workspace protocol (rehr_conv5_thin_f32_workspace_bytes).
+ * Replaces rehr_conv_small_cout_{fwd,dgrad,wgrad}_f32 for sr_head.2 where the shape qualifies. */
+int64_t rehr_conv5_thin_f32_workspace_bytes(const rehr_direct_conv_desc* d);
+int rehr_conv5_thin_f32_supported(const rehr_direct_conv_desc* d);
+int rehr_conv5_thin_fwd_f32(const rehr_direct_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
+int rehr_conv5_thin_dgrad_f32(const rehr_direct_conv_desc* d, float* dx, int32_t lddx, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+int rehr_conv5_thin_wgrad_f32(const rehr_direct_conv_desc* d, float* dw, float* dbias, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Training-patch feed from HBM-resident volumes.
  * Replaces the host-side numpy chain of utils/train_set.py:100-160 (TrainSetMultipleSegSREfficient.__getitem__),

@@ -701,56 +701,64 @@ def axis_resample(x, axis, idx, w):
 
 
 # ----------------------------------------------------------------------------- sr_head.2 on the bf16 matrix cores
-def _thin5_ws(d, dev):
-    n = int(L.load().rehr_conv5_thin_workspace_bytes(C.byref(d)))
+def _thin5_ws(d, dev, f32=False):
+    fn = L.load().rehr_conv5_thin_f32_workspace_bytes if f32 else L.load().rehr_conv5_thin_workspace_bytes
+    n = int(fn(C.byref(d)))
     if n < 0:
         L.check(n, "rehr_conv5_thin_workspace_bytes")
     return torch.empty((n + 3) // 4, dtype=torch.float32, device=dev), n
 
 
-def thin5_supported(x_shape, w_shape, pad):
-    """Conv3d(16 -> 2, 5x5x5, stride 1, pad 2) with W % 32 == 0, W <= 160: the shapes the MFMA kernels take."""
+USE_THIN5_F32 = True   # sr_head.2 of the fp32 path on the fp32 matrix cores (False: the VALU kernels of direct_conv.hip)
+
+
+def thin5_supported(x_shape, w_shape, pad, dtype=torch.bfloat16):
+    """Conv3d(16 -> 2, 5x5x5, stride 1, pad 2) with W % 32 == 0 and W <= 160 (bf16) / 128 (fp32): the shapes the
+    matrix-core kernels of thin_conv_{bf16,f32}.hip take."""
     N, Cin, D, H, W = x_shape
+    if dtype == torch.float32 and not USE_THIN5_F32:
+        return False
+    es, wmax = (2, 160) if dtype == torch.bfloat16 else (4, 128)
     return (tuple(w_shape) == (2, 16, 5, 5, 5) and Cin == 16 and tuple(pad) == (2, 2, 2) and W % 32 == 0
-            and 32 <= W <= 160 and D * H * W * 16 * 2 < 2 ** 32)
+            and 32 <= W <= wmax and D * H * W * 16 * es < 2 ** 32 and dtype in (torch.bfloat16, torch.float32))
 
 
 def thin5_fwd(x, w, bias):
-    """y (fp32) = conv3d(x (bf16 NDHWC), w, bias) for sr_head.2 (rehr_conv5_thin_fwd_bf16)."""
+    """y (fp32) = conv3d(x (bf16 or fp32 NDHWC), w, bias) for sr_head.2 (rehr_conv5_thin_fwd_{bf16,f32})."""
     _chk_dev(x, w, bias)
-    if x.dtype != torch.bfloat16:
-        raise L.RehrsegHipError("thin5_fwd: bf16 activations")
     N, Cin, D, H, W = x.shape
     y = new_act(N, 2, D, H, W, like=x, dtype=torch.float32)
     d = _direct_desc(x, w.contiguous(), bias, y, (1, 1, 1), (2, 2, 2), 0, 0.0, None, 0)
-    ws, n = _thin5_ws(d, x.device)
-    L.check(L.load().rehr_conv5_thin_fwd_bf16(C.byref(d), _ptr(ws), n, _stream()), "rehr_conv5_thin_fwd_bf16")
+    f32 = x.dtype == torch.float32
+    ws, n = _thin5_ws(d, x.device, f32)
+    fn, name = _fn("rehr_conv5_thin_fwd", x)
+    L.check(fn(C.byref(d), _ptr(ws), n, _stream()), name)
     return y
 
 
-def thin5_dgrad(dy, w):
-    """dx (bf16 NDHWC, 16 channels) of sr_head.2 from dY (fp32 NDHWC, 2 channels)."""
+def thin5_dgrad(dy, w, dtype=torch.bfloat16):
+    """dx (NDHWC, 16 channels, `dtype`) of sr_head.2 from dY (fp32 NDHWC, 2 channels)."""
     _chk_dev(dy, w)
     if dy.dtype != torch.float32:
         raise L.RehrsegHipError("thin5_dgrad: fp32 output gradient")
     N, _, D, H, W = dy.shape
-    dx = new_act(N, 16, D, H, W, like=dy, dtype=torch.bfloat16)
+    dx = new_act(N, 16, D, H, W, like=dy, dtype=dtype)
     d = _direct_desc(dx, w.contiguous(), None, dy, (1, 1, 1), (2, 2, 2), 0, 0.0, None, 0)
-    ws, n = _thin5_ws(d, dy.device)
-    L.check(L.load().rehr_conv5_thin_dgrad_bf16(C.byref(d), _ptr(dx), 16, _ptr(ws), n, _stream()),
-            "rehr_conv5_thin_dgrad_bf16")
+    ws, n = _thin5_ws(d, dy.device, dtype == torch.float32)
+    fn, name = _fn("rehr_conv5_thin_dgrad", dx)
+    L.check(fn(C.byref(d), _ptr(dx), 16, _ptr(ws), n, _stream()), name)
     return dx
 
 
 def thin5_wgrad(x, w, dy, want_bias=False):
-    """(dw (2,16,5,5,5), db) fp32 of sr_head.2 from x (bf16) and dY (fp32)."""
+    """(dw (2,16,5,5,5), db) fp32 of sr_head.2 from x (bf16 or fp32) and dY (fp32)."""
     _chk_dev(x, w, dy)
-    if x.dtype != torch.bfloat16 or dy.dtype != torch.float32:
-        raise L.RehrsegHipError("thin5_wgrad: bf16 activations, fp32 output gradient")
+    if dy.dtype != torch.float32:
+        raise L.RehrsegHipError("thin5_wgrad: fp32 output gradient")
     d = _direct_desc(x, w.contiguous(), None, dy, (1, 1, 1), (2, 2, 2), 0, 0.0, None, 0)
-    ws, n = _thin5_ws(d, x.device)
+    ws, n = _thin5_ws(d, x.device, x.dtype == torch.float32)
     dw = torch.empty_like(w, memory_format=torch.contiguous_format)
     db = torch.empty(2, dtype=torch.float32, device=x.device) if want_bias else None
-    L.check(L.load().rehr_conv5_thin_wgrad_bf16(C.byref(d), _ptr(dw), _ptr(db), _ptr(ws), n, _stream()),
-            "rehr_conv5_thin_wgrad_bf16")
+    fn, name = _fn("rehr_conv5_thin_wgrad", x)
+    L.check(fn(C.byref(d), _ptr(dw), _ptr(db), _ptr(ws), n, _stream()), name)
     return dw, db

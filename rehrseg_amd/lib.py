@@ -137,6 +137,11 @@ PROTOTYPES = {
     "rehr_quad_maxpool_fwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_quad_maxpool_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_window_stem_assemble_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, C.c_float, _vp]),
+    "rehr_conv5_thin_f32_workspace_bytes": (_i64, [_P_DC]),
+    "rehr_conv5_thin_f32_supported": (C.c_int, [_P_DC]),
+    "rehr_conv5_thin_fwd_f32": (C.c_int, [_P_DC, _vp, _i64, _vp]),
+    "rehr_conv5_thin_dgrad_f32": (C.c_int, [_P_DC, _vp, _i32, _vp, _i64, _vp]),
+    "rehr_conv5_thin_wgrad_f32": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),
     "rehr_conv5_thin_workspace_bytes": (_i64, [_P_DC]),
     "rehr_conv5_thin_dgrad_bf16": (C.c_int, [_P_DC, _vp, _i32, _vp, _i64, _vp]),
     "rehr_conv5_thin_wgrad_bf16": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),

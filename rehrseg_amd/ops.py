@@ -216,6 +216,12 @@ def _thin_out(w, cfg: ConvCfg, has_x2):
             cfg.stride == (1, 1, 1) and w.shape[4] <= 7)
 
 
+def _thin5_f32(be, x, w, cfg: ConvCfg, shape=None):
+    """sr_head.2 (16 -> 2, 5x5x5) in fp32 on a shape the fp32 matrix-core kernels take (thin_conv_f32.hip)."""
+    return (x.dtype == torch.float32 and x.is_cuda and hasattr(be, "thin5_supported") and
+            be.thin5_supported(tuple(shape if shape is not None else x.shape), tuple(w.shape), cfg.pad, torch.float32))
+
+
 def _sub_taps(t, a, b):
     """taps [a, b) of one axis' arithmetic tap description."""
     cnt, off0, offs, k0, ks = t
@@ -279,6 +285,8 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
             if act != ACT_NONE:
                 raise NotImplementedError("activation behind the bf16 thin-output conv")
             return be.thin5_fwd(x1, w, bias), None
+        if act == ACT_NONE and _thin5_f32(be, x1, w, cfg):
+            return be.thin5_fwd(x1, w, bias), None
         y = be.new_act(N, Cout, *out_dims, like=x1)
         be.small_cout_fwd(x1, w, bias, y, cfg.pad, act, slope)
         return y, None
@@ -323,6 +331,8 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True, x_d
     if _thin_out(w, cfg, c2 > 0):
         if x_dtype == torch.bfloat16:
             return (be.thin5_dgrad(dz.float() if dz.dtype != torch.float32 else dz, w) if need1 else None), None
+        if dz.dtype == torch.float32 and _thin5_f32(be, dz, w, cfg, (N, c1) + tuple(in_dims)):
+            return (be.thin5_dgrad(dz, w, torch.float32) if need1 else None), None
         return (be.small_cout_dgrad(dz, w, (N, c1) + tuple(in_dims), cfg.pad) if need1 else None), None
     out = []
     for (lo, cnt, need) in ((0, c1, need1), (c1, c2, need2)):
@@ -431,6 +441,8 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
     if _thin_out(w, cfg, x2 is not None):
         if x1.dtype == torch.bfloat16:
             return be.thin5_wgrad(x1, w, dz.float() if dz.dtype != torch.float32 else dz, want_bias)
+        if dz.dtype == torch.float32 and _thin5_f32(be, x1, w, cfg):
+            return be.thin5_wgrad(x1, w, dz, want_bias)
         return be.small_cout_wgrad(x1, w, dz, cfg.pad, want_bias)
     dw = out if out is not None else torch.empty(tuple(w.shape), dtype=w.dtype, device=w.device)
     db = None

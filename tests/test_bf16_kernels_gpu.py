@@ -285,3 +285,52 @@ def test_upmix_bf16_matches_fp32():
     db32 = hb.channel_sum_actgrad(dy.float(), y16.float(), 1, 0.0)
     db16 = hb.channel_sum_actgrad(dy, y16, 1, 0.0)
     torch.testing.assert_close(db16, db32, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 5, 32), (2, 7, 6, 64), (1, 12, 9, 96), (1, 33, 13, 128)])
+def test_thin5_conv_fp32_vs_fp64(shape):
+    """The same layer on the fp32 matrix cores (thin_conv_f32.hip; the fp32 path's sr_head.2) against torch in float64
+    on the host: forward, input gradient, weight + bias gradient within 1e-5 of the largest value."""
+    import torch.nn.functional as F
+    from rehrseg_amd import hip_backend as hb
+    N, D, H, W = shape
+    assert hb.thin5_supported((N, 16, D, H, W), (2, 16, 5, 5, 5), (2, 2, 2), torch.float32)
+    assert not hb.thin5_supported((N, 16, D, H, 160), (2, 16, 5, 5, 5), (2, 2, 2), torch.float32)
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + 1)
+    x = torch.randn(N, 16, D, H, W, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn(2, 16, 5, 5, 5, generator=g) * 0.05
+    b = torch.randn(2, generator=g)
+    dy = torch.randn(N, 2, D, H, W, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+
+    def close(a, ref, tol):
+        assert a.dtype == torch.float32
+        assert (a.double().cpu() - ref).abs().max() <= tol * ref.abs().max()
+
+    close(hb.thin5_fwd(x.to(DEV), w.to(DEV), b.to(DEV)), F.conv3d(xd, wd, b.double(), padding=2), 1e-5)
+    close(hb.thin5_dgrad(dy.to(DEV), w.to(DEV), torch.float32), torch.nn.grad.conv3d_input(xd.shape, wd, dyd, padding=2), 1e-5)
+    dw, db = hb.thin5_wgrad(x.to(DEV), w.to(DEV), dy.to(DEV), True)
+    close(dw, torch.nn.grad.conv3d_weight(xd, w.shape, dyd, padding=2), 1e-5)
+    close(db, dyd.sum((0, 2, 3, 4)), 1e-5)
+
+
+def test_sr_head_fp32_routes_to_matrix_cores():
+    """fused_conv3d on the sr_head.2 shape in fp32: forward and both gradients agree with the VALU kernels they replace."""
+    from rehrseg_amd import hip_backend as hb
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(1, 16, 9, 6, 64, generator=g).to(DEV).requires_grad_()
+    w = (torch.randn(2, 16, 5, 5, 5, generator=g) * 0.05).to(DEV).requires_grad_()
+    b = torch.randn(2, generator=g).to(DEV).requires_grad_()
+    gy = torch.randn(1, 2, 9, 6, 64, generator=g).to(DEV)
+    y = ops.fused_conv3d(x, w, b, 1, 2)
+    got = torch.autograd.grad(y, (x, w, b), gy)
+    saved = hb.thin5_supported
+    hb.thin5_supported = lambda *a, **k: False          # the VALU kernels of direct_conv.hip
+    try:
+        y2 = ops.fused_conv3d(x, w, b, 1, 2)
+        want = torch.autograd.grad(y2, (x, w, b), gy)
+    finally:
+        hb.thin5_supported = saved
+    torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5)
+    for a, e in zip(got, want):
+        torch.testing.assert_close(a, e, rtol=1e-4, atol=1e-4)

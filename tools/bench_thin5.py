@@ -29,11 +29,13 @@ def timed(fn, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32"))
     args = ap.parse_args()
+    DT = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    for (N, D, H, W) in ((1, 12, 10, 32), (2, 40, 30, 64), (1, 23, 9, 96), (2, 512, 128, 128), (1, 640, 160, 160)):
+    for (N, D, H, W) in ((1, 12, 10, 32), (2, 40, 30, 64), (1, 23, 9, 96), (2, 512, 128, 128), (1, 640, 160, 160))[:4 if args.dtype == "fp32" else 5]:
         x = torch.randn(N, 16, D, H, W, device=dev).contiguous(memory_format=torch.channels_last_3d)
-        xb = x.to(torch.bfloat16)
+        xb = x.to(DT)
         w = torch.randn(2, 16, 5, 5, 5, device=dev) * 0.05
         b = torch.randn(2, device=dev)
         small = D * H * W < 2 ** 18
@@ -41,32 +43,32 @@ def main():
         if args.only in (None, "fwd"):
             y = hb.thin5_fwd(xb, w, b)
             if small:
-                ref = F.conv3d(xb.float(), w.to(torch.bfloat16).float(), b, padding=2)
+                ref = F.conv3d(xb.float(), w.to(DT).float(), b, padding=2)
                 err = ((y - ref).abs().max() / ref.abs().max()).item()
             else:  # against the fp32 VALU kernel on the same rounded operands
-                ref, _ = ops.conv_forward(xb.float(), None, w.to(torch.bfloat16).float(), b, ops.ConvCfg((1, 1, 1), (2, 2, 2)), 0, 0.0, 0)
+                ref, _ = ops.conv_forward(xb.float(), None, w.to(DT).float(), b, ops.ConvCfg((1, 1, 1), (2, 2, 2)), 0, 0.0, 0)
                 err = ((y - ref).abs().max() / ref.abs().max()).item()
             t = timed(lambda: hb.thin5_fwd(xb, w, b))
             t0 = timed(lambda: ops.conv_forward(x, None, w, b, ops.ConvCfg((1, 1, 1), (2, 2, 2)), 0, 0.0, 0))
             print(f"fwd  {(N, D, H, W)}: max rel err {err:.2e}  mfma {t * 1e6:8.1f} us ({flop / t / 1e12:6.1f} TF alg)  "
                   f"valu fp32 {t0 * 1e6:8.1f} us", flush=True)
         dy = torch.randn(N, 2, D, H, W, device=dev).contiguous(memory_format=torch.channels_last_3d)
-        dyb = dy.to(torch.bfloat16).float()
-        wb = w.to(torch.bfloat16).float()
+        dyb = dy.to(DT).float()
+        wb = w.to(DT).float()
         cfg = ops.ConvCfg((1, 1, 1), (2, 2, 2))
         if args.only in (None, "dgrad"):
-            dx = hb.thin5_dgrad(dy, w).float()
+            dx = hb.thin5_dgrad(dy, w, DT).float()
             if small:
                 ref = torch.nn.grad.conv3d_input(x.shape, wb, dyb, padding=2)
             else:
                 ref, _ = ops.conv_dgrad(dyb, wb, (D, H, W), 16, 0, cfg)
             err = ((dx - ref).abs().max() / ref.abs().max()).item()   # includes the bf16 rounding of the result
-            t = timed(lambda: hb.thin5_dgrad(dy, w))
+            t = timed(lambda: hb.thin5_dgrad(dy, w, DT))
             t0 = timed(lambda: ops.conv_dgrad(dy, w, (D, H, W), 16, 0, cfg))
             print(f"dgrad{(N, D, H, W)}: max rel err {err:.2e}  mfma {t * 1e6:8.1f} us ({flop / t / 1e12:6.1f} TF alg)  "
                   f"valu fp32 {t0 * 1e6:8.1f} us", flush=True)
         if args.only in (None, "wgrad"):
-            dw = hb.thin5_wgrad(xb, w, dy)
+            dw, _ = hb.thin5_wgrad(xb, w, dy)
             if small:
                 ref = torch.nn.grad.conv3d_weight(xb.float(), w.shape, dyb, padding=2)
             else:
