@@ -673,9 +673,10 @@ def patch_gather(items, dims, scale=1.0, bias=0.0):
     return out
 
 
-def axis_resample(x, axis, idx, w):
+def axis_resample(x, axis, idx, w, validated=False):
     """y[..., j, ...] = sum_t w[j, t] * x[..., idx[j, t], ...] along `axis` (idx < 0 drops the term); x contiguous float32
-    on the device, idx int32 [n_out, taps], w float32 [n_out, taps] (device)."""
+    on the device, idx int32 [n_out, taps], w float32 [n_out, taps] (device).  `validated`: the caller has already
+    checked idx < x.shape[axis] on the host (saves the device round trip of the check here)."""
     _chk_dev(x, w)
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise L.RehrsegHipError("axis_resample: contiguous float32 input")
@@ -683,7 +684,7 @@ def axis_resample(x, axis, idx, w):
         raise L.RehrsegHipError("axis_resample: idx int32 / w float32 tables of one [n_out, taps] shape on the device")
     axis = axis % x.dim()
     n_in = x.shape[axis]
-    if idx.numel() and int(idx.max()) >= n_in:
+    if not validated and idx.numel() and int(idx.max()) >= n_in:
         raise L.RehrsegHipError("axis_resample: tap index beyond the axis")
     outer = 1
     for s in x.shape[:axis]:

@@ -240,16 +240,31 @@ def blur_taps(n, kernel):
     return idx, w
 
 
+def _check_taps(idx, n_in):
+    if idx.size and int(idx.max()) >= n_in:
+        raise ValueError("tap index beyond the axis")
+
+
 def _resample(x, axis, table):
     idx, w = table
-    return hb.axis_resample(x.contiguous(), axis, torch.from_numpy(idx).to(x.device), torch.from_numpy(w).to(x.device))
+    _check_taps(idx, x.shape[axis])
+    return hb.axis_resample(x.contiguous(), axis, torch.from_numpy(idx).to(x.device), torch.from_numpy(w).to(x.device),
+                            validated=True)
+
+
+_tap_cache = {}   # (n_in, dx, order, device) -> (idx, w) on the device: the tables of a training run never change
 
 
 def resize_axis(x, axis, dx, order):
     """`resize` along one axis of a device tensor (see resize_taps; unpinned)."""
     if dx == 1:
         return x
-    return _resample(x, axis, resize_taps(x.shape[axis], dx, order))
+    key = (x.shape[axis], float(dx), order, x.device)
+    if key not in _tap_cache:
+        idx, w = resize_taps(x.shape[axis], dx, order)
+        _check_taps(idx, x.shape[axis])
+        _tap_cache[key] = (torch.from_numpy(idx).to(x.device), torch.from_numpy(w).to(x.device))
+    return hb.axis_resample(x.contiguous(), axis, *_tap_cache[key], validated=True)
 
 
 # ----------------------------------------------------------------------------- containers

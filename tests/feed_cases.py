@@ -56,7 +56,7 @@ def emu_patch_gather(items, dims, scale=1.0, bias=0.0):
     return torch.from_numpy(out)
 
 
-def emu_axis_resample(x, axis, idx, w):
+def emu_axis_resample(x, axis, idx, w, validated=False):
     a = np.moveaxis(x.detach().cpu().numpy(), axis, 0)
     idx, w = idx.cpu().numpy(), w.cpu().numpy()
     out = np.zeros((idx.shape[0],) + a.shape[1:], np.float32)
