@@ -213,10 +213,16 @@ int wgrad_blocks(const rehr_direct_conv_desc& d, int64_t* vpb) {
 
 }  // namespace
 
+int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream);   // thin_cin_conv.hip: fp32 matrix cores
+
 extern "C" int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* dp, void* stream) {
   if (!dp || !small_cin_ok(*dp)) return REHR_EINVAL;
   const rehr_direct_conv_desc& d = *dp;
   if (d.stats_mode != 0 && !d.stats) return REHR_EINVAL;
+  {
+    const int rc = thin_cin_fwd_try(d, (hipStream_t)stream);   // C_out 32 / 64, kW <= 8, stride_w <= 2
+    if (rc != REHR_ENOSUP) return rc;
+  }
   const int T = d.KD * d.KH * d.KW;
   const size_t smem = (size_t)d.Cin * T * d.Cout * sizeof(float);
   if (smem > 150 * 1024) return REHR_ENOSUP;

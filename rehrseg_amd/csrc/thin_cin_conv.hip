@@ -1,0 +1,213 @@
+// Thin-INPUT convolutions (C_in = 1 or 2: the network input) on the fp32 matrix cores: the first nnU-Net conv
+// (Conv3d(1, 32, 3x3x3 or 1x3x3), dynamic_network_architectures' first StackedConvBlocks, built at train_all.py:474-493)
+// and the FLAVR stem Conv3d(img_channels, 64, (3,7,7), stride (1,2,2)) (models/FLAVR/resnet_3D.py:47-48), incl. the
+// per-slice (1,7,7) responses of the teacher's overlapping windows (train_all.py:85-112).  The vector-pipe kernel of
+// direct_conv.hip runs them at 14-26 TFLOP/s (one x load + 4 LDS reads per 16 FMAs: issue bound): 0.64 ms of a cfg-3
+// step, 2.0 ms of cfg-5.
+//
+// GEMM per 16 output voxels along w:  C[m = c_out][n = voxel] += A[m][k] * B[k][n] on v_mfma_f32_16x16x4_f32 with
+// k = (row r = (ci, kd, kh), group g of 4 kw taps, kq = kw - 4g): the kq index of the instruction is the kw tap, so a
+// lane's B value is the input patch at (row, x = voxel * sw + 4g + kq) -- one LDS dword at (lane base + immediate),
+// no index arithmetic in the loop; kw is padded to a multiple of 4 with zero weights (3 -> 4, 7 -> 8).
+// A block stages the input patch of its output tile (4 rows x 64 or 32 columns, wave = row) and ALL weights in LDS
+// ([k step][kq][c_out], loaded once per block; blocks walk several tiles), every A dword feeds NV voxel tiles and every
+// B dword all c_out tiles.  M = c_out makes the accumulator quad of a lane 4 consecutive channels of one voxel: 16-byte
+// NDHWC stores.  Epilogue: bias, activation, fp64 statistics of the stored values (one atomic per channel and block).
+#include "common.h"
+
+namespace {
+
+struct ThinCinParams {
+  rehr_direct_conv_desc d;
+  int G;            // kw groups of 4
+  int ksteps;       // Cin * KD * KH * G
+  int PH, PW;       // patch rows / padded columns (floats)
+  int tiles_h, tiles_w, tiles_per_img, tiles_per_block;
+};
+
+template <int NTN, int NV>   // c_out tiles (Cout = 16 NTN), voxel tiles per wave
+__global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const ThinCinParams p) {
+  const rehr_direct_conv_desc& d = p.d;
+  constexpr int COUT = 16 * NTN, COLS = 16 * NV, ROWS = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;                                   // [ksteps][4][COUT]
+  float* Ps = smem + (size_t)p.ksteps * 4 * COUT;     // [Cin*KD][PH][PW]
+  float* red = Ps;                                    // statistics scratch (the patch is idle then)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_img = blockIdx.y;
+
+  // weights -> LDS, zero for the padded kw taps
+  for (int i = tid; i < p.ksteps * 4 * COUT; i += 256) {
+    const int co = i % COUT, kq = (i / COUT) & 3, ks = i / (4 * COUT);
+    const int g = ks % p.G, r = ks / p.G;
+    const int kh = r % d.KH, kd = (r / d.KH) % d.KD, ci = r / (d.KH * d.KD);
+    const int kw = 4 * g + kq;
+    Wl[i] = kw < d.KW ? d.w[(((int64_t)(co * d.Cin + ci) * d.KD + kd) * d.KH + kh) * d.KW + kw] : 0.f;
+  }
+
+  const int nn = lane & 15, kq = lane >> 4;
+  float bv[NTN][4];
+#pragma unroll
+  for (int mt = 0; mt < NTN; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[mt][i] = d.bias ? d.bias[mt * 16 + 4 * kq + i] : 0.f;
+  float s1[NTN][4], s2[NTN][4];
+#pragma unroll
+  for (int mt = 0; mt < NTN; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s1[mt][i] = 0.f; s2[mt][i] = 0.f; }
+
+  const float* xn = d.x + (int64_t)n_img * d.Di * d.Hi * d.Wi * d.ldx;
+  float* yn = d.y + (int64_t)n_img * d.Do * d.Ho * d.Wo * d.ldy;
+  const int planes = d.Cin * d.KD;
+  const int patch = planes * p.PH * p.PW;
+  const int t_begin = blockIdx.x * p.tiles_per_block;
+  const int t_end = min(p.tiles_per_img, t_begin + p.tiles_per_block);
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tw = tile % p.tiles_w;
+    const int th = (tile / p.tiles_w) % p.tiles_h;
+    const int od = tile / (p.tiles_w * p.tiles_h);
+    const int oh0 = th * ROWS, ow0 = tw * COLS;
+    const int id0 = od * d.sd - d.pd, ih0 = oh0 * d.sh - d.ph, iw0 = ow0 * d.sw - d.pw;
+    __syncthreads();   // the previous tile's patch reads (and the weight stores of the first round) are done
+    for (int i = tid; i < patch; i += 256) {
+      const int px = i % p.PW, py = (i / p.PW) % p.PH, pl = i / (p.PW * p.PH);
+      const int kd = pl % d.KD, ci = pl / d.KD;
+      const int id = id0 + kd, ih = ih0 + py, iw = iw0 + px;
+      const bool ok = ((unsigned)id < (unsigned)d.Di) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+      Ps[i] = ok ? xn[(((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx + ci] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 acc[NV][NTN];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int mt = 0; mt < NTN; ++mt) acc[v][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane base inside the patch: output row `wave`, voxel nn of tile 0, tap kq
+    const float* pb = Ps + (wave * d.sh) * p.PW + nn * d.sw + kq;
+    const float* wb = Wl + kq * COUT + nn;
+    int ks = 0;
+    for (int pl = 0; pl < planes; ++pl) {
+      for (int kh = 0; kh < d.KH; ++kh) {
+        const float* prow = pb + (pl * p.PH + kh) * p.PW;
+        for (int g = 0; g < p.G; ++g, ++ks) {
+          float a[NTN], b[NV];
+#pragma unroll
+          for (int mt = 0; mt < NTN; ++mt) a[mt] = wb[ks * 4 * COUT + mt * 16];
+#pragma unroll
+          for (int v = 0; v < NV; ++v) b[v] = prow[v * 16 * d.sw + 4 * g];
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int mt = 0; mt < NTN; ++mt)
+              acc[v][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[v], acc[v][mt], 0, 0, 0);
+        }
+      }
+    }
+
+    const int oh = oh0 + wave;
+    if (oh < d.Ho) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int ow = ow0 + v * 16 + nn;
+        if (ow < d.Wo) {
+          float* yo = yn + (((int64_t)od * d.Ho + oh) * d.Wo + ow) * d.ldy + 4 * kq;
+#pragma unroll
+          for (int mt = 0; mt < NTN; ++mt) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float r = apply_act(acc[v][mt][i] + bv[mt][i], d.act, d.slope);
+              o[i] = r;
+              s1[mt][i] += r;
+              s2[mt][i] += r * r;
+            }
+            *reinterpret_cast<f32x4*>(yo + mt * 16) = o;
+          }
+        }
+      }
+    }
+  }
+
+  if (d.stats_mode != 0) {   // lanes of one kq hold the same channels: sum over the 16 voxel lanes, then the 4 waves
+#pragma unroll
+    for (int mt = 0; mt < NTN; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[mt][i] += __shfl_xor(s1[mt][i], o, 64);
+          s2[mt][i] += __shfl_xor(s2[mt][i], o, 64);
+        }
+      }
+    __syncthreads();
+    if (nn == 0) {
+#pragma unroll
+      for (int mt = 0; mt < NTN; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = mt * 16 + 4 * kq + i;
+          red[(wave * 2 + 0) * COUT + c] = s1[mt][i];
+          red[(wave * 2 + 1) * COUT + c] = s2[mt][i];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * COUT; c += 256) {
+      const int st = c / COUT, ch = c % COUT;
+      float s = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) s += red[(w4 * 2 + st) * COUT + ch];
+      if (st == 0 || d.stats_mode == 2) atomicAdd(d.stats + ((int64_t)n_img * d.Cout + ch) * 2 + st, (double)s);
+    }
+  }
+}
+
+}  // namespace
+
+// rehr_conv_small_cin_fwd_f32 tries this first; REHR_ENOSUP = not a shape for it
+int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream) {
+  if (d.Cin < 1 || d.Cin > 2 || (d.Cout != 32 && d.Cout != 64) || d.KW > 8 || d.sw < 1 || d.sw > 2 || d.ldy % 4 ||
+      (reinterpret_cast<uintptr_t>(d.y) & 15))
+    return REHR_ENOSUP;
+  ThinCinParams p;
+  p.d = d;
+  p.G = (d.KW + 3) / 4;
+  p.ksteps = d.Cin * d.KD * d.KH * p.G;
+  const int NTN = d.Cout / 16, NV = d.Cout == 32 ? 4 : 2, COLS = 16 * NV;
+  p.PH = 3 * d.sh + d.KH;
+  p.PW = (COLS - 1) * d.sw + 4 * p.G;
+  p.PW += (p.PW & 1) ? 0 : 1;                       // odd row pitch
+  const size_t wbytes = (size_t)p.ksteps * 4 * d.Cout * sizeof(float);
+  size_t pbytes = (size_t)d.Cin * d.KD * p.PH * p.PW * sizeof(float);
+  const size_t rbytes = (size_t)4 * 2 * d.Cout * sizeof(float);
+  if (pbytes < rbytes) pbytes = rbytes;
+  const size_t smem = wbytes + pbytes;
+  if (smem > 150 * 1024) return REHR_ENOSUP;
+  p.tiles_h = (d.Ho + 3) / 4;
+  p.tiles_w = (d.Wo + COLS - 1) / COLS;
+  const int64_t tpi = (int64_t)d.Do * p.tiles_h * p.tiles_w;
+  if (tpi >= ((int64_t)1 << 31)) return REHR_ENOSUP;
+  p.tiles_per_img = (int)tpi;
+  // blocks walk runs of tiles: the weights are loaded once per block, statistics cost one atomic per channel and block
+  int64_t bx = tpi;
+  const int64_t cap = 1024 / d.N > 0 ? 1024 / d.N : 1;
+  if (bx > cap) bx = cap;
+  p.tiles_per_block = (int)((tpi + bx - 1) / bx);
+  bx = (tpi + p.tiles_per_block - 1) / p.tiles_per_block;
+  dim3 grid((unsigned)bx, d.N);
+#define TCI_LAUNCH(NTN_, NV_)                                                                                        \
+  do {                                                                                                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cin_fwd_kernel<NTN_, NV_>),                           \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)                   \
+      return REHR_EHIP;                                                                                              \
+    hipLaunchKernelGGL((thin_cin_fwd_kernel<NTN_, NV_>), grid, dim3(256), smem, stream, p);                          \
+  } while (0)
+  if (NTN == 2) TCI_LAUNCH(2, 4);
+  else TCI_LAUNCH(4, 2);
+#undef TCI_LAUNCH
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}

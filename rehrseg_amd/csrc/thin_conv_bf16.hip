@@ -591,23 +591,39 @@ __global__ __launch_bounds__(64 * NW) void thin_wgrad_kernel(const ThinWgradPara
 }
 
 // dw (2,16,5,5,5) = sum over block slabs, fixed order; slab index [(kd*5 + kw)][ci][kh*2 + co]
-__global__ void thin_wgrad_reduce_kernel(const float* __restrict__ slabs, int nblocks, float* __restrict__ dw,
-                                         float* __restrict__ dbias) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // index into dw
-  if (i >= 2 * TC_CIN * 125) {
-    const int co = i - 2 * TC_CIN * 125;
-    if (co < 2 && dbias != nullptr) {
-      double sd = 0.0;
-      for (int bq = 0; bq < nblocks; ++bq) sd += (double)slabs[(int64_t)bq * TW_SLABF + TW_SLAB + co];
-      dbias[co] = (float)sd;
-    }
-    return;
+// 8 threads share an output element (thread (e, g) sums the blocks g, g + 8, ...; fixed-order combine through LDS): one
+// thread per element walking every block's slab was a 0.29 ms latency chain at 160^3
+__global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float* __restrict__ slabs, int nblocks, float* __restrict__ dw,
+                                                             float* __restrict__ dbias) {
+  constexpr int G = 8, EPB = 256 / G, NDW = 2 * TC_CIN * 125;
+  __shared__ float part[256];
+  const int el = threadIdx.x % EPB, g = threadIdx.x / EPB;
+  const int i = blockIdx.x * EPB + el;   // index into dw (2,16,5,5,5), then the two bias gradients
+  int si = -1;
+  if (i < NDW) {
+    const int kw = i % 5, kh = (i / 5) % 5, kd = (i / 25) % 5, ci = (i / 125) % TC_CIN, co = i / (125 * TC_CIN);
+    si = ((kd * 5 + kw) * 16 + ci) * 16 + kh * 2 + co;
+  } else if (i < NDW + 2) {
+    si = TW_SLAB + (i - NDW);
   }
-  const int kw = i % 5, kh = (i / 5) % 5, kd = (i / 25) % 5, ci = (i / 125) % TC_CIN, co = i / (125 * TC_CIN);
-  const int si = ((kd * 5 + kw) * 16 + ci) * 16 + kh * 2 + co;
-  float s = 0.f;
-  for (int bq = 0; bq < nblocks; ++bq) s += slabs[(int64_t)bq * TW_SLABF + si];
-  dw[i] = s;
+  float s0 = 0.f, s1 = 0.f;
+  if (si >= 0) {
+    int bq = g;
+    for (; bq + G < nblocks; bq += 2 * G) {
+      s0 += slabs[(int64_t)bq * TW_SLABF + si];
+      s1 += slabs[(int64_t)(bq + G) * TW_SLABF + si];
+    }
+    for (; bq < nblocks; bq += G) s0 += slabs[(int64_t)bq * TW_SLABF + si];
+  }
+  part[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && si >= 0) {
+    float s = part[el];
+#pragma unroll
+    for (int q = 1; q < G; ++q) s += part[q * EPB + el];
+    if (i < NDW) dw[i] = s;
+    else if (dbias != nullptr) dbias[i - NDW] = s;
+  }
 }
 
 }  // namespace
@@ -708,7 +724,7 @@ extern "C" int rehr_conv5_thin_wgrad_bf16(const rehr_direct_conv_desc* dp, float
   const size_t smem = (size_t)2 * TC_BH * (d.Wi + 4) * 32 + (size_t)TD_RING * TW_ROWS * 2 * (d.Wi * 2 + 16);
   TC_SWITCH(thin_wgrad_kernel, TC_T64N)
   REHR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((2 * TC_CIN * 125 + 2 + 255) / 256), dim3(256), 0, st, p.slabs,
+  hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((2 * TC_CIN * 125 + 2 + 31) / 32), dim3(256), 0, st, p.slabs,
                      (int)blocks, dw, dbias);
   REHR_LAUNCH_CHECK();
   return REHR_OK;

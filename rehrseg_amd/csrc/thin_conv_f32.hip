@@ -527,30 +527,39 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
   }
 }
 
-__global__ void thinf_wgrad_reduce_kernel(const float* __restrict__ slabs, int nblocks, float* __restrict__ dw,
-                                          float* __restrict__ dbias) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // index into dw (2,16,5,5,5)
-  if (i >= 2 * TF_CIN * 125) {
-    const int co = i - 2 * TF_CIN * 125;
-    if (co < 2 && dbias != nullptr) {
-      double sd = 0.0;
-      for (int bq = 0; bq < nblocks; ++bq) sd += (double)slabs[(int64_t)bq * TF_SLABF + TF_SLAB + co];
-      dbias[co] = (float)sd;
+// 8 threads share an output element (thread (e, g) sums the blocks g, g + 8, ...; fixed-order combine through LDS): one
+// thread per element walking every block's slab was a 0.29 ms latency chain at 160^3
+__global__ __launch_bounds__(256) void thinf_wgrad_reduce_kernel(const float* __restrict__ slabs, int nblocks, float* __restrict__ dw,
+                                                             float* __restrict__ dbias) {
+  constexpr int G = 8, EPB = 256 / G, NDW = 2 * TF_CIN * 125;
+  __shared__ float part[256];
+  const int el = threadIdx.x % EPB, g = threadIdx.x / EPB;
+  const int i = blockIdx.x * EPB + el;   // index into dw (2,16,5,5,5), then the two bias gradients
+  int si = -1;
+  if (i < NDW) {
+    const int kw = i % 5, kh = (i / 5) % 5, kd = (i / 25) % 5, ci = (i / 125) % TF_CIN, co = i / (125 * TF_CIN);
+    si = ((kd * 5 + kw) * 16 + ci) * 16 + kh * 2 + co;
+  } else if (i < NDW + 2) {
+    si = TF_SLAB + (i - NDW);
+  }
+  float s0 = 0.f, s1 = 0.f;
+  if (si >= 0) {
+    int bq = g;
+    for (; bq + G < nblocks; bq += 2 * G) {
+      s0 += slabs[(int64_t)bq * TF_SLABF + si];
+      s1 += slabs[(int64_t)(bq + G) * TF_SLABF + si];
     }
-    return;
+    for (; bq < nblocks; bq += G) s0 += slabs[(int64_t)bq * TF_SLABF + si];
   }
-  const int kw = i % 5, kh = (i / 5) % 5, kd = (i / 25) % 5, ci = (i / 125) % TF_CIN, co = i / (125 * TF_CIN);
-  const int si = ((kd * 5 + kw) * 16 + ci) * 16 + kh * 2 + co;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int bq = 0;
-  for (; bq + 3 < nblocks; bq += 4) {
-    s0 += slabs[(int64_t)bq * TF_SLABF + si];
-    s1 += slabs[(int64_t)(bq + 1) * TF_SLABF + si];
-    s2 += slabs[(int64_t)(bq + 2) * TF_SLABF + si];
-    s3 += slabs[(int64_t)(bq + 3) * TF_SLABF + si];
+  part[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && si >= 0) {
+    float s = part[el];
+#pragma unroll
+    for (int q = 1; q < G; ++q) s += part[q * EPB + el];
+    if (i < NDW) dw[i] = s;
+    else if (dbias != nullptr) dbias[i - NDW] = s;
   }
-  for (; bq < nblocks; ++bq) s0 += slabs[(int64_t)bq * TF_SLABF + si];
-  dw[i] = (s0 + s1) + (s2 + s3);
 }
 
 bool thinf_shape_ok(const rehr_direct_conv_desc& d) {
@@ -658,7 +667,7 @@ extern "C" int rehr_conv5_thin_wgrad_f32(const rehr_direct_conv_desc* dp, float*
   const size_t smem = (size_t)2 * TF_BH * (d.Wi + 4) * 64 + (size_t)TF_RING * TF_ROWS * 2 * (d.Wi * 4 + 16);
   TF_SWITCH(thinf_wgrad_kernel, TF_T64N)
   REHR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(thinf_wgrad_reduce_kernel, dim3((2 * TF_CIN * 125 + 2 + 255) / 256), dim3(256), 0, st, p.slabs,
+  hipLaunchKernelGGL(thinf_wgrad_reduce_kernel, dim3((2 * TF_CIN * 125 + 2 + 31) / 32), dim3(256), 0, st, p.slabs,
                      (int)blocks, dw, dbias);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
