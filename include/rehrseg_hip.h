@@ -99,13 +99,16 @@ typedef struct {
    * (same fp32 results up to the transform's rounding, ~1e-6 relative).          */
   float* wino_ws;
   int64_t wino_ws_bytes;
-  int32_t flags;                   /* REHR_GG_* bits (bf16 entry points only; the fp32 ones ignore it) */
+  int32_t flags;                   /* REHR_GG_* bits */
 } rehr_gather_gemm_desc;
 
 /* bf16 entry points: store y as fp32 instead of bf16 (logits, features handed to fp32 losses) */
 #define REHR_GG_Y_F32 1
 /* bf16 entry points: never take the LDS halo-brick kernel (tests compare it with the per-tap gather kernel) */
 #define REHR_GG_NO_HALO 2
+
+/* fp32 entry points: the eight-wave organisation of the big-tile Winograd kernel (two waves per SIMD) */
+#define REHR_GG_WINO_8WAVE 4
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);

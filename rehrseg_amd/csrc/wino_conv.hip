@@ -664,6 +664,301 @@ __global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) 
 }
 
 // ------------------------------------------------------------------------------------------
+// Eight-wave organisation of the big-tile kernel (same tile, LDS layout, weight panel and output transform): wave =
+// (Winograd row r, tile group fm), two waves per SIMD with 128 accumulator registers each.  The four-wave kernel above
+// gives one wave a whole SIMD: whatever stalls its in-order instruction stream (an LDS fragment not yet back, the
+// barrier, a weight load) idles the matrix pipe -- measured on 512->512 @ 128x16x16: 1.71 ms against 1.43 ms of MFMA
+// time + prologue / epilogue, 1.63 ms with the LDS reads removed, 1.67 ms without the barrier.  With a second resident
+// wave the pipe has somebody else to serve; the price is that both tile-group waves of a row fetch the same weight
+// fragments (L1 hits) and that the software pipeline is shallower (128 VGPRs): weights of (k-group, channel group)
+// arrive one half k-group ahead, A fragments one k-group ahead.
+constexpr int NX8 = (PVOX2 * 8 + 511) / 512;   // 16-byte pieces staged per thread (6)
+
+__global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p) {
+  const rehr_gather_gemm_desc& d = p.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;  // [2][BUF2]; reused as the row-combine exchange buffer at the end
+  constexpr int BUF = BUF2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = wv & 3, fm = wv >> 2;
+  const int half = lane >> 5, col = lane & 31;
+  const int part = (p.nsplit > 1) ? (int)(blockIdx.z % p.nsplit) : 0;
+  const int n_img = (p.nsplit > 1) ? (int)(blockIdx.z / p.nsplit) : (int)blockIdx.z;
+  const rehr_axis_taps td = (p.nsplit > 1) ? p.s_td[part] : p.d.td;
+  const float* const up = (p.nsplit > 1) ? p.s_up[part] : p.up;
+  const uint32_t up_bytes = (p.nsplit > 1) ? p.s_up_bytes[part] : p.up_bytes;
+  float* const yout = (p.nsplit > 1) ? p.s_y[part] : p.d.y;
+  const int nt0 = blockIdx.y * 2, n0 = blockIdx.y * 64;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int bw_ = b % p.nb_w; b /= p.nb_w;
+  const int bh_ = b % p.nb_h;
+  const int od = b / p.nb_h;
+  const int oh0 = bh_ * 16, ow0 = bw_ * 16;
+
+  const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
+  const float s2 = (r == 1) ? 1.f : -1.f;
+  const float rsign = (r == 2) ? -1.f : 1.f;
+  const int th_ = fm * 4 + (col >> 3), tw_ = col & 7;
+  const float* xa = Xs + (2 * th_ + i1) * RP2 + tw_ * LDX + 4 * half;
+  const float* xb = Xs + (2 * th_ + i2) * RP2 + tw_ * LDX + 4 * half;
+
+  int pvx[NX8];
+  uint32_t pok = 0;
+#pragma unroll
+  for (int i = 0; i < NX8; ++i) {
+    const int piece = tid + 512 * i;
+    const int v = piece >> 3;
+    const int ph = v / PW2, slot = v - ph * PW2;
+    const int pw_ = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
+    const int ih = oh0 + p.dh0 + ph, iw = ow0 + p.dw0 + pw_;
+    const bool ok = (piece < PVOX2 * 8) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+    pvx[i] = ok ? ih * d.Wi + iw : 0;
+    pok |= (ok ? 1u : 0u) << i;
+  }
+  const int pq = tid & 7;
+  const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
+  constexpr int NXH = NX8 / 2;   // pieces per staging half
+  f32x4 rx[NXH];
+  int jd_lo = td.count, jd_hi = -1;
+  for (int j = 0; j < td.count; ++j) {
+    const int id = od + d.bd + td.off0 + td.offs * j;
+    if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
+  }
+  const int items = p.kchunks * max(0, jd_hi - jd_lo + 1);
+  struct Item { int chunk, jd; };
+  auto advance = [&](Item& t) {
+    if (++t.jd > jd_hi) { t.jd = jd_lo; ++t.chunk; }
+  };
+  auto fetch = [&](const Item& t, const int lo) {   // pieces lo .. lo + NXH - 1
+    const bool live = (t.chunk < p.kchunks) & (items > 0);
+    const int jd = t.jd;
+    const int cc = (live ? t.chunk : 0) * 32;
+    const int id = od + d.bd + td.off0 + td.offs * jd;
+    const bool first = cc < d.c1;
+    const float* src = first ? d.x1 : d.x2;
+    const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
+    const int coff = first ? cc : cc - d.c1;
+    const uint32_t nrec = img_elems * ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(src) + (int64_t)n_img * img_elems * ld, 0, nrec, 0x00020000);
+    const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
+    const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
+#pragma unroll
+    for (int i = 0; i < NXH; ++i) {
+      const bool ok = dok & ((pok >> (lo + i)) & 1u);
+      const uint32_t off = base + (uint32_t)pvx[lo + i] * ld * 4u;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
+    }
+  };
+  auto stage = [&](int buf, const int lo) {
+#pragma unroll
+    for (int i = 0; i < NXH; ++i) {
+      const int piece = tid + 512 * (lo + i);
+      const int v = piece >> 3, row = (v * 3641) >> 16;  // v / 18 for v < 1024
+      if (piece < PVOX2 * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LDX + row * 8 + pq * 4) = rx[i];
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rsu =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(up), 0, up_bytes, 0x00020000);
+  const int NT = d.Npad / 32;
+  const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
+  const uint32_t ulane = (uint32_t)lane * 16u;
+  const uint32_t ubase = (uint32_t)(r * 4) * xi_stride + (uint32_t)nt0 * nt_stride;
+  auto load_u = [&](const Item& t, const int kk, const int fn, f32x4 (&ub)[4]) {
+    const int chunk = t.chunk < p.kchunks ? t.chunk : 0;  // (one item past the end is requested, never used)
+    const uint32_t base = ubase + (uint32_t)(t.jd * 16) * xi_stride + (uint32_t)(chunk * 4 + kk) * 1024u + fn * nt_stride;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, base + c * xi_stride, 0));
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[fn][c][q] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  auto issue_reads = [&](int buf, const int kk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * LDX + kk * 8);
+      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * LDX + kk * 8);
+    }
+  };
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  struct VFrag { f32x2 p[4][2]; };
+  const f32x2 s2v = {s2, s2};
+  auto combine = [&](VFrag& v) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x2 R[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 a = h ? ra[j].hi : ra[j].lo, bq = h ? rb[j].hi : rb[j].lo;
+        R[j] = __builtin_elementwise_fma(bq, s2v, a);
+      }
+      v.p[0][h] = R[0] - R[2];
+      v.p[1][h] = R[1] + R[2];
+      v.p[2][h] = R[1] - R[2];  // negated column, undone at the output
+      v.p[3][h] = R[1] - R[3];
+    }
+  };
+  auto mfmas = [&](const int fn, const VFrag& v, const f32x4 (&ub)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[fn][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.p[c][e >> 1][e & 1], ub[c][e], acc[fn][c], 0, 0, 0);
+  };
+
+  VFrag VA, VB;
+  f32x4 u0[4], u1[4];   // weights of channel group 0 / 1 of the current k-group
+  Item ci = {0, min(jd_lo, td.count - 1)}, ni = ci;
+  fetch(ci, 0);
+  stage(0, 0);
+  fetch(ci, NXH);
+  load_u(ci, 0, 0, u0);
+  load_u(ci, 0, 1, u1);
+  stage(0, NXH);
+  __syncthreads();
+  issue_reads(0, 0);
+  combine(VA);
+
+  // half step = (k-group kk, channel group fn) = 16 MFMAs; behind them: the weights this half step has just released
+  // are re-loaded for the next k-group, the A fragments of the next k-group are read and combined, the next item's
+  // patch is fetched (kk 0, 2) and staged (kk 1, 3)
+#define BIG8_KGROUP(kk, vcur, vnext, NEXT_T, NEXT_KK, READS, EXTRA0, EXTRA1)  \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  READS;                                                                      \
+  EXTRA0;                                                                     \
+  mfmas(0, vcur, u0);                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  load_u(NEXT_T, NEXT_KK, 0, u0);                                             \
+  EXTRA1;                                                                     \
+  mfmas(1, vcur, u1);                                                         \
+  combine(vnext);                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  load_u(NEXT_T, NEXT_KK, 1, u1);
+
+  for (int it = 0; it < items; ++it) {
+    const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
+    advance(ni);
+    BIG8_KGROUP(0, VA, VB, ci, 1, issue_reads(cur, 1), fetch(ni, 0), (void)0)
+    BIG8_KGROUP(1, VB, VA, ci, 2, issue_reads(cur, 2), (void)0, stage(nxt, 0))
+    BIG8_KGROUP(2, VA, VB, ci, 3, issue_reads(cur, 3), fetch(ni, NXH), (void)0)
+    // last k-group of the item: its A fragments are in VB; the next item's come after the barrier
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(0, VB, u0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(ni, 0, 0, u0);
+    stage(nxt, NXH);
+    mfmas(1, VB, u1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(ni, 0, 1, u1);
+    __syncthreads();
+    issue_reads(nxt, 0);
+    combine(VA);
+    ci = ni;
+  }
+#undef BIG8_KGROUP
+  __syncthreads();
+
+  // ---- output transform: columns in registers, rows across the 4 row-waves of a tile group through LDS
+  float* ex = smem;  // [fm*2+fn][r][c'][q][lane]
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn) {
+    const f32x16 T0 = (acc[fn][0] + acc[fn][1] - acc[fn][2]) * rsign;
+    const f32x16 T1 = (acc[fn][1] + acc[fn][2] - acc[fn][3]) * rsign;
+    float* e0 = ex + (((fm * 2 + fn) * 4 + r) * 2) * 16 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      e0[q * 64] = T0[q];
+      e0[(16 + q) * 64] = T1[q];
+    }
+  }
+  __syncthreads();
+  const int ro = r >> 1, co = r & 1;
+  const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
+  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
+  float ssum[2][2];
+  float* ybase = yout + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
+                 n0 + col;
+  const int64_t rowstep = 2 * (int64_t)d.Wy * d.ldy, colstep = 2 * (int64_t)d.ldy;
+  const bool interior = (oh0 + 16 <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 64 <= d.Cout);
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn) {
+    const int col_n = n0 + fn * 32 + col;
+    const bool colok = col_n < d.Cout;
+    const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
+    float s1_ = 0.f, s2_ = 0.f;
+    const float* e0 = ex + ((fm * 2 + fn) * 4 * 2 + co) * 16 * 64 + lane;
+    float t[4][16];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + k3 * t[3][q] + bv;
+      v[q] = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
+    }
+    float* yb = ybase + fn * 32 + (fm * 4) * rowstep;
+    if (interior) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
+        s1_ += v[q];
+        s2_ += v[q] * v[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
+        const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
+        if (ok) yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
+        s1_ += ok ? v[q] : 0.f;
+        s2_ += ok ? v[q] * v[q] : 0.f;
+      }
+    }
+    ssum[fn][0] = s1_ + __shfl_xor(s1_, 32, 64);
+    ssum[fn][1] = s2_ + __shfl_xor(s2_, 32, 64);
+  }
+  if (d.stats_mode != 0) {  // block-level sums first: one atomic per column and block
+    __syncthreads();  // everybody is done reading ex
+    float* red = smem;   // [wave 8][fn 2][2][32]
+    if (half == 0) {
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn) {
+        red[((wv * 2 + fn) * 2 + 0) * 32 + col] = ssum[fn][0];
+        red[((wv * 2 + fn) * 2 + 1) * 32 + col] = ssum[fn][1];
+      }
+    }
+    __syncthreads();
+    if (wv < 2 && half == 0) {  // wave fn sums the eight waves' partials of its 32 columns
+      const int fn = wv, col_n = n0 + fn * 32 + col;
+      if (col_n < d.Cout) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          a1 += red[((w * 2 + fn) * 2 + 0) * 32 + col];
+          a2 += red[((w * 2 + fn) * 2 + 1) * 32 + col];
+        }
+        double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
+        atomicAdd(st, (double)a1);
+        if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Wide-tile variant for 32-wide output-channel tiles (nnU-Net stage-0 / last decoder stage, SR
 // head): 128 Winograd tiles (32 x 16 outputs of one depth slice) x 32 channels per block, one block
 // of 16 waves per CU (wave = Winograd row x tile group, 4 accumulator tiles each).  The four tile
@@ -992,11 +1287,13 @@ int wino_conv_split_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t 
   p.nb_w = (d0.Lw + 15) / 16;
   const size_t smem_x = (size_t)2 * BUF2 * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
   const size_t smem = smem_x > smem_e ? smem_x : smem_e;
-  if (hipFuncSetAttribute((const void*)wino_conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
-      hipSuccess)
+  const bool w8 = (d0.flags & REHR_GG_WINO_8WAVE) != 0;
+  if (hipFuncSetAttribute(w8 ? (const void*)wino_conv_big8_kernel : (const void*)wino_conv_big_kernel,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return REHR_EHIP;
   dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d0.Ld), d0.Npad / 64, d0.N * count);
-  hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
+  if (w8) hipLaunchKernelGGL(wino_conv_big8_kernel, grid, dim3(512), smem, stream, p);
+  else hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -1054,7 +1351,18 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
       attr_set = true;
     }
     dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 64, d.N);
-    hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
+    if (d.flags & REHR_GG_WINO_8WAVE) {
+      static bool attr_set8 = false;
+      if (!attr_set8) {
+        if (hipFuncSetAttribute((const void*)wino_conv_big8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+          return REHR_EHIP;
+        attr_set8 = true;
+      }
+      hipLaunchKernelGGL(wino_conv_big8_kernel, grid, dim3(512), smem, stream, p);
+    } else {
+      hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
+    }
     REHR_LAUNCH_CHECK();
     return REHR_OK;
   }

@@ -152,6 +152,7 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
 USE_WINOGRAD = True
 USE_WINOGRAD_WGRAD = True
 USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps
+USE_WINO_8WAVE = True   # fp32 big-tile Winograd kernel: two waves per SIMD (wino_conv_big8_kernel)
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
 wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
 
@@ -197,6 +198,8 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             global wino_launches
             wino_launches += 1
             d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
+            if USE_WINO_8WAVE:
+                d.flags = L.GG_WINO_8WAVE
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
