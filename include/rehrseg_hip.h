@@ -109,6 +109,8 @@ typedef struct {
 
 /* fp32 entry points: the eight-wave organisation of the big-tile Winograd kernel (two waves per SIMD) */
 #define REHR_GG_WINO_8WAVE 4
+/* fp32 entry points: the 32-channel-tile Winograd kernel with one 1024-thread block per CU instead of two 512-thread ones */
+#define REHR_GG_W32_ONE_PER_CU 8
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
@@ -182,6 +184,8 @@ typedef struct {
  * Everything that selects a kernel travels in the descriptors: the library reads no environment
  * variables and keeps no mutable state between calls. */
 #define REHR_WGRAD_DIRECT 1
+/* Winograd weight gradient of layers with >= 64 channels on both sides: two 64 x 32 blocks per CU instead of one 64 x 64 */
+#define REHR_WGRAD_TWO_PER_CU 2
 
 /* Mixed-precision weight gradient: l and g point at bf16 elements (ld* in elements, % 8 == 0; Ca, Cg % 8 == 0),
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 slabs and fp32 dst (the master-weight gradient).  dbias must

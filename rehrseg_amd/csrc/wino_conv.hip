@@ -965,12 +965,20 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
 // groups share every weight fragment through L1/L2, so the small-tile kernel's weight traffic per
 // MFMA from L2 (its limiter: 2 blocks/CU on different tiles) drops.  K items are 16-channel half chunks so that the 34 x 18 patch double-buffers in
 // LDS (row pitch 368 floats, even/odd column split: conflict-free fragment reads).
-constexpr int W3_ROWS = 34, W3_LD = 20, W3_RP = PW2 * W3_LD + 8, W3_BUF = W3_ROWS * W3_RP;
-constexpr int W3_VOX = W3_ROWS * PW2;                 // 612 patch voxels
-constexpr int W3_NX = (W3_VOX * 4 + 255) / 256;       // 10 16-byte pieces per thread
-constexpr int W3_FMOFF = 8 * W3_RP;                   // next tile group = 4 tile rows = 8 patch rows
+constexpr int W3_LD = 20, W3_RP = PW2 * W3_LD + 8;
+// NFM = tile groups of 32 tiles (4 tile rows) per block: 4 (32 x 16 outputs, 16 waves, one block per CU) or 2
+// (16 x 16 outputs, 8 waves, 64 KB of LDS: TWO blocks per CU).  With 32 input channels a tile's K loop is 6 items
+// (~26 us) against ~10 us of launch + first fetch + epilogue per block (K loop run twice: 0.580 -> 1.004 ms on
+// 32->32 @ 128^3); two independent blocks on a CU run one's fixed part under the other's K loop, which a persistent
+// single block (tried: 0.623 ms) cannot.
+template <int NFM> struct W3 {
+  static constexpr int ROWS = 8 * NFM + 2, BUF = ROWS * W3_RP, VOX = ROWS * PW2, NTHR = 256 * NFM;
+  static constexpr int NXT = (VOX * 4 + NTHR - 1) / NTHR;
+};
 
-__global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p) {
+template <int NFM>
+__global__ __launch_bounds__(256 * NFM, NFM == 2 ? 2 : 1) void wino_conv_w32_kernel(const WinoParams p) {
+  constexpr int W3_BUF = W3<NFM>::BUF, W3_VOX = W3<NFM>::VOX, NTHR = W3<NFM>::NTHR;
   const rehr_gather_gemm_desc& d = p.d;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;  // [2][W3_BUF]; reused as the exchange buffer at the end
@@ -989,7 +997,7 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
   const int bw_ = b % p.nb_w; b /= p.nb_w;
   const int bh_ = b % p.nb_h;
   const int od = b / p.nb_h;
-  const int oh0 = bh_ * 32, ow0 = bw_ * 16;
+  const int oh0 = bh_ * (8 * NFM), ow0 = bw_ * 16;
 
   const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
   const float s2 = (r == 1) ? 1.f : -1.f;
@@ -999,12 +1007,12 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
   const float* xb = Xs + (2 * th_ + i2) * W3_RP + tw_ * W3_LD + 4 * half;
 
   // staging pieces (LDS order: 4 pieces = 16 channels per voxel slot), 3 per thread
-  constexpr int NXT = (W3_VOX * 4 + 1023) / 1024;
+  constexpr int NXT = W3<NFM>::NXT;
   int pvx[NXT];
   uint32_t pok = 0;
 #pragma unroll
   for (int i = 0; i < NXT; ++i) {
-    const int piece = tid + 1024 * i;
+    const int piece = tid + NTHR * i;
     const int v = piece >> 2;
     const int ph = v / PW2, slot = v - ph * PW2;
     const int pw_ = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
   auto stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NXT; ++i) {
-      const int piece = tid + 1024 * i;
+      const int piece = tid + NTHR * i;
       const int v = piece >> 2, row = (v * 3641) >> 16;  // v / 18 for v < 1024
       if (piece < W3_VOX * 4) *reinterpret_cast<f32x4*>(Xs + buf + v * W3_LD + row * 8 + pq * 4) = rx[i];
     }
@@ -1135,7 +1143,7 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
   float* ybase = d.y + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
                  n0 + col;
   const int64_t rowstep = 2 * (int64_t)d.Wy * d.ldy, colstep = 2 * (int64_t)d.ldy;
-  const bool interior = (oh0 + 32 <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 32 <= d.Cout);
+  const bool interior = (oh0 + 8 * NFM <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 32 <= d.Cout);
   const int col_n = n0 + col;
   const bool colok = col_n < d.Cout;
   const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
     s1_ += __shfl_xor(s1_, 32, 64);
     s2_ += __shfl_xor(s2_, 32, 64);
     __syncthreads();  // everybody is done reading ex
-    float* red = smem;  // [wave 16][2][32]
+    float* red = smem;  // [wave 4 NFM][2][32]
     if (half == 0) {
       red[(wv * 2 + 0) * 32 + col] = s1_;
       red[(wv * 2 + 1) * 32 + col] = s2_;
@@ -1185,7 +1193,7 @@ __global__ __launch_bounds__(1024) void wino_conv_w32_kernel(const WinoParams p)
     if (wv == 0 && half == 0 && colok) {
       float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) {
+      for (int w = 0; w < 4 * NFM; ++w) {
         a1 += red[(w * 2 + 0) * 32 + col];
         a2 += red[(w * 2 + 1) * 32 + col];
       }
@@ -1203,9 +1211,33 @@ bool three_taps(const rehr_axis_taps& t, int b) {
 }
 
 bool w32_ok(const rehr_gather_gemm_desc& d) {
-  if (d.Npad % 64 == 0 || d.Lh < 32 || d.Lw < 16) return false;  // 64-multiples: the big-tile kernel is faster
-  const int64_t nb_h = (d.Lh + 31) / 32, nb_w = (d.Lw + 15) / 16;
-  return nb_h * 32 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13;
+  if (d.Npad % 64 == 0 || d.Lh < 16 || d.Lw < 16) return false;  // 64-multiples: the big-tile kernel is faster
+  const int64_t nb_h = (d.Lh + 15) / 16, nb_w = (d.Lw + 15) / 16;
+  return nb_h * 16 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13;
+}
+// four tile groups per block (one block per CU) or two (two blocks per CU)
+int w32_groups(const rehr_gather_gemm_desc& d) {
+  if (d.flags & REHR_GG_W32_ONE_PER_CU) {
+    const int64_t nb_h = (d.Lh + 31) / 32, nb_w = (d.Lw + 15) / 16;
+    if (d.Lh >= 32 && nb_h * 32 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13) return 4;
+  }
+  return 2;
+}
+
+template <int NFM>
+int launch_w32(const WinoParams& p, const rehr_gather_gemm_desc& d, hipStream_t stream) {
+  const size_t smem_x = (size_t)2 * W3<NFM>::BUF * sizeof(float), smem_e = (size_t)NFM * 4 * 2 * 16 * 64 * sizeof(float);
+  const size_t smem = smem_x > smem_e ? smem_x : smem_e;
+  static bool attr_set32 = false;
+  if (!attr_set32) {
+    if (hipFuncSetAttribute((const void*)wino_conv_w32_kernel<NFM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return REHR_EHIP;
+    attr_set32 = true;
+  }
+  dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 32, d.N);
+  hipLaunchKernelGGL(wino_conv_w32_kernel<NFM>, grid, dim3(256 * NFM), smem, stream, p);
+  return REHR_OK;
 }
 
 bool big_ok(const rehr_gather_gemm_desc& d) {
@@ -1317,19 +1349,11 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wino_weights_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws,
                        p.kchunks);
-    p.nb_h = (d.Lh + 31) / 32;
+    const int nfm = w32_groups(d);
+    p.nb_h = (d.Lh + 8 * nfm - 1) / (8 * nfm);
     p.nb_w = (d.Lw + 15) / 16;
-    const size_t smem_x = (size_t)2 * W3_BUF * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
-    const size_t smem = smem_x > smem_e ? smem_x : smem_e;
-    static bool attr_set32 = false;
-    if (!attr_set32) {
-      if (hipFuncSetAttribute((const void*)wino_conv_w32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)smem) != hipSuccess)
-        return REHR_EHIP;
-      attr_set32 = true;
-    }
-    dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 32, d.N);
-    hipLaunchKernelGGL(wino_conv_w32_kernel, grid, dim3(1024), smem, stream, p);
+    const int rc = nfm == 4 ? launch_w32<4>(p, d, stream) : launch_w32<2>(p, d, stream);
+    if (rc != REHR_OK) return rc;
     REHR_LAUNCH_CHECK();
     return REHR_OK;
   }

@@ -36,6 +36,7 @@ struct WWParams {
   int items, items_per_split, splits;
   int a_tiles, c_tiles, Capad, Cgpad;
   int fa, fb;
+  bool two;      // 64 x 32 blocks, two per CU
   // narrow planes (Lw < 16, e.g. the 12x12 layers of the reference's 96x96 crops): G consecutive (sample, depth)
   // slices are laid side by side, each with a 1-column zero gutter on either side, into a virtual lattice of
   // width G*(Lw+2) -- a pure index map in the fetch; dY is zero in the gutters, so whatever the transform
@@ -64,8 +65,10 @@ struct WWCfg {
   static constexpr int MINB = (FA * FB == 4) ? 1 : ((FA * FB == 2) ? 1 : 2);
 };
 
-template <int FA, int FB, bool VIRT>
-__global__ __launch_bounds__(256, (WWCfg<FA, FB>::MINB)) void wino_wgrad_kernel(const WWParams p) {
+// MINB_ = resident blocks per CU the register budget is cut for: the 64 x 32 shape also runs two blocks per CU (two
+// waves per SIMD, 256 registers each) for the 64 x 64-and-wider layers -- see plan()
+template <int FA, int FB, bool VIRT, int MINB_ = WWCfg<FA, FB>::MINB>
+__global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p) {
   using C = WWCfg<FA, FB>;
   constexpr int WP = C::WP, CA = C::CA, CG = C::CG, YBUF = C::YBUF, BUF = C::BUF;
   constexpr int NPY = C::NPY, NPXM = C::NPXM, NP = C::NP, NPA = C::NPA;
@@ -475,17 +478,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const WWParams p
   }
 }
 
-template <int FA, int FB, bool VIRT>
+template <int FA, int FB, bool VIRT, int MINB_ = WWCfg<FA, FB>::MINB>
 int launch_ww(const WWParams& p, dim3 grid, hipStream_t stream) {
   const size_t smem = ((size_t)2 * WWCfg<FA, FB>::BUF + 128) * sizeof(float);  // + the spare pad of stage()
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<FA, FB, VIRT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<FA, FB, VIRT, MINB_>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
       return REHR_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wino_wgrad_kernel<FA, FB, VIRT>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((wino_wgrad_kernel<FA, FB, VIRT, MINB_>), grid, dim3(256), smem, stream, p);
   return REHR_OK;
 }
 
@@ -532,6 +535,10 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   p.items = (int)items;
   p.fa = (d.Ca <= 32) ? 1 : 2;  // 32-channel sides take a single 32-wide group
   p.fb = (d.Cg <= 32) ? 1 : 2;
+  // two 64 x 32 blocks per CU instead of one 64 x 64 block (REHR_WGRAD_TWO_PER_CU): a second wave per SIMD fills the
+  // issue gaps of the first; dY is then staged by both blocks of a pair
+  p.two = (d.flags & REHR_WGRAD_TWO_PER_CU) && p.fa == 2 && p.fb == 2;
+  if (p.two) p.fb = 1;
   p.a_tiles = (d.Ca + p.fa * 32 - 1) / (p.fa * 32);
   p.c_tiles = (d.Cg + p.fb * 32 - 1) / (p.fb * 32);
   p.Capad = p.a_tiles * p.fa * 32;
@@ -546,7 +553,7 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
     return false;
   // split count: fill whole rounds of 256 single-block CUs, >= 16 stages per block
   const int tiles = p.a_tiles * p.c_tiles * d.td.count;
-  const int slots = 256 * ((p.fa * p.fb == 1) ? 2 : 1);  // resident blocks
+  const int slots = 256 * ((p.fa * p.fb == 1 || p.two) ? 2 : 1);  // resident blocks
   int best_s = 1;
   double best_eff = 0.0;
   for (int k = 1; k <= 4; ++k) {
@@ -592,6 +599,7 @@ int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
   if (p.fa == 2 && p.fb == 2) rc = virt ? launch_ww<2, 2, true>(p, grid, stream) : launch_ww<2, 2, false>(p, grid, stream);
   else if (p.fa == 1 && p.fb == 1) rc = virt ? launch_ww<1, 1, true>(p, grid, stream) : launch_ww<1, 1, false>(p, grid, stream);
   else if (p.fa == 1) rc = virt ? launch_ww<1, 2, true>(p, grid, stream) : launch_ww<1, 2, false>(p, grid, stream);
+  else if (p.two) rc = virt ? launch_ww<2, 1, true, 2>(p, grid, stream) : launch_ww<2, 1, false, 2>(p, grid, stream);
   else rc = virt ? launch_ww<2, 1, true>(p, grid, stream) : launch_ww<2, 1, false>(p, grid, stream);
   if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)d.td.count * d.Ca * d.Cg;

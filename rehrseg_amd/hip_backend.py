@@ -152,6 +152,8 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
 USE_WINOGRAD = True
 USE_WINOGRAD_WGRAD = True
 USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps
+USE_WGRAD_TWO_PER_CU = False  # Winograd weight gradient: two 64 x 32 blocks per CU for the >= 64-channel layers
+USE_W32_TWO_PER_CU = False # fp32 32-channel-tile Winograd kernel: two 512-thread blocks per CU (False: one of 1024)
 USE_WINO_8WAVE = True   # fp32 big-tile Winograd kernel: two waves per SIMD (wino_conv_big8_kernel)
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
 wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
@@ -198,8 +200,7 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             global wino_launches
             wino_launches += 1
             d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
-            if USE_WINO_8WAVE:
-                d.flags = L.GG_WINO_8WAVE
+            d.flags = (L.GG_WINO_8WAVE if USE_WINO_8WAVE else 0) | (0 if USE_W32_TWO_PER_CU else L.GG_W32_ONE_PER_CU)
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
@@ -277,7 +278,7 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     d.dst_sa, d.dst_sc, d.dst_st = dst_strides
     d.accumulate = int(accumulate)
     d.dbias = _ptr(dbias)
-    d.flags = 0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT
+    d.flags = (0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT) | (L.WGRAD_TWO_PER_CU if USE_WGRAD_TWO_PER_CU else 0)
     lib = L.load()
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
     if bf16:

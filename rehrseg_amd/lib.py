@@ -17,9 +17,11 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rehrseg_hip.h")
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 ABI_VERSION = 2
 WGRAD_DIRECT = 1  # rehr_wgrad_desc.flags
+WGRAD_TWO_PER_CU = 2
 GG_Y_F32 = 1      # rehr_gather_gemm_desc.flags
 GG_NO_HALO = 2
 GG_WINO_8WAVE = 4
+GG_W32_ONE_PER_CU = 8
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p
