@@ -966,11 +966,10 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
 // MFMA from L2 (its limiter: 2 blocks/CU on different tiles) drops.  K items are 16-channel half chunks so that the 34 x 18 patch double-buffers in
 // LDS (row pitch 368 floats, even/odd column split: conflict-free fragment reads).
 constexpr int W3_LD = 20, W3_RP = PW2 * W3_LD + 8;
-// NFM = tile groups of 32 tiles (4 tile rows) per block: 4 (32 x 16 outputs, 16 waves, one block per CU) or 2
-// (16 x 16 outputs, 8 waves, 64 KB of LDS: TWO blocks per CU).  With 32 input channels a tile's K loop is 6 items
-// (~26 us) against ~10 us of launch + first fetch + epilogue per block (K loop run twice: 0.580 -> 1.004 ms on
-// 32->32 @ 128^3); two independent blocks on a CU run one's fixed part under the other's K loop, which a persistent
-// single block (tried: 0.623 ms) cannot.
+// NFM = tile groups of 32 tiles (4 tile rows) per block: 4 (32 x 16 outputs, 16 waves, one block per CU; default) or 2
+// (16 x 16 outputs, 8 waves, 64 KB of LDS: two blocks per CU, REHR_GG_W32_ONE_PER_CU not set by the caller).  Measured
+// equal (32->32 @ 128^3: 0.574 vs 0.580 ms per call, cfg-3 unchanged), like a persistent one-block-per-CU version with
+// next-tile prefetch before it (0.623 ms): the kernel's 0.58 matrix-pipe utilisation is not a per-block fixed cost.
 template <int NFM> struct W3 {
   static constexpr int ROWS = 8 * NFM + 2, BUF = ROWS * W3_RP, VOX = ROWS * PW2, NTHR = 256 * NFM;
   static constexpr int NXT = (VOX * 4 + NTHR - 1) / NTHR;
