@@ -180,7 +180,11 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   const uint32_t ulane = (uint32_t)(r * 3) * xi_stride + (uint32_t)nt0 * nt_stride + (uint32_t)lane * 16u;
   auto load_u = [&](const Item& t, int kk, f32x4 (&ub)[3]) {
     const int ph_i = t.ph < p.nphase ? t.ph : 0;  // (one item past the end is requested and never used)
+#ifdef W22_DBG_SAMEW   // (timing diagnostics only: every k-group reads the same, cache-hot fragments)
+    const uint32_t base = ulane + 0u * (uint32_t)(ph_i + kk);
+#else
     const uint32_t base = (uint32_t)((ph_i * d.td.count + t.jd) * 9) * xi_stride + (uint32_t)(t.chunk * 4 + kk) * 1024u + ulane;
+#endif
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride, 0, 0));
@@ -194,12 +198,16 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
 
   auto kstep = [&](int buf, const int kk, const f32x4 (&ub)[3]) {
     f32x4 R[3];
+#ifdef W22_DBG_NOLDS   // (timing diagnostics only: wrong results)
+    R[0] = R[1] = R[2] = ub[0];
+#else
 #pragma unroll
     for (int j = 0; j < 3; ++j) R[j] = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
     if (r != 1) {  // wave-uniform: the middle Winograd row is the patch row itself
 #pragma unroll
       for (int j = 0; j < 3; ++j) R[j] -= *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
     }
+#endif
     f32x4 v[3];
     v[0] = R[0] - R[1];
     v[1] = R[1];
@@ -232,7 +240,9 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
     kstep(cur, 3, u1);
     stage(nxt);
     cur_i = nxt_i;
+#ifndef W22_DBG_NOBAR
     __syncthreads();
+#endif
   }
 
   // ---- output transform Y = A^T M A, A^T = [[1,1,0],[0,1,1]]: columns in registers, rows through LDS

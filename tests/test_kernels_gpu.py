@@ -421,3 +421,63 @@ def test_cosine_distance_loss_fused():
     (g,) = torch.autograd.grad(loss, ag)
     (gr,) = torch.autograd.grad(ref, ar)
     _close(g, gr, 1e-4)
+
+
+# ----------------------------------------------------------------------------- kernel-organisation variants
+@pytest.mark.parametrize("Cin,Cout,dims", [(64, 64, (5, 40, 48)), (96, 128, (3, 32, 32)), (64, 192, (4, 32, 48))])
+def test_winograd_eight_wave_kernel_is_bit_identical(Cin, Cout, dims):
+    """wino_conv_big8_kernel (two waves per SIMD, default) against wino_conv_big_kernel (one): same tile, same panel,
+    same summation order -> the same bits, statistics epilogue included."""
+    from rehrseg_amd import hip_backend as hb
+    x = _mk(2, Cin, *dims, seed=61).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = (_mk(Cout, Cin, 3, 3, 3, seed=62) / (27 * Cin) ** 0.5).to(_dev())
+    b = _mk(Cout, seed=63).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    saved = hb.USE_WINO_8WAVE
+    try:
+        out = {}
+        for flag in (False, True):
+            hb.USE_WINO_8WAVE = flag
+            before = hb.wino_launches
+            out[flag] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.01, 2)
+            assert hb.wino_launches > before
+    finally:
+        hb.USE_WINO_8WAVE = saved
+    assert torch.equal(out[True][0], out[False][0])
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-6, atol=1e-6)   # fp32 block partials: other grouping
+
+
+def test_winograd_w32_two_per_cu_variant():
+    """wino_conv_w32_kernel<2> (two 512-thread blocks per CU) against <4> (one of 1024): same arithmetic per tile."""
+    from rehrseg_amd import hip_backend as hb
+    x = _mk(2, 32, 4, 64, 48, seed=64).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = (_mk(32, 32, 3, 3, 3, seed=65) / (27 * 32) ** 0.5).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    saved = hb.USE_W32_TWO_PER_CU
+    try:
+        out = {}
+        for flag in (False, True):
+            hb.USE_W32_TWO_PER_CU = flag
+            out[flag] = ops.conv_forward(x, None, w, None, cfg, 0, 0.0, 2)
+    finally:
+        hb.USE_W32_TWO_PER_CU = saved
+    assert torch.equal(out[True][0], out[False][0])
+
+
+def test_winograd_wgrad_two_per_cu_variant():
+    """REHR_WGRAD_TWO_PER_CU (two 64 x 32 blocks per CU) against the 64 x 64 blocking: same products, another split."""
+    from rehrseg_amd import hip_backend as hb
+    x = _mk(2, 64, 4, 32, 32, seed=66).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    dy = _mk(2, 128, 4, 32, 32, seed=67).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = _mk(128, 64, 3, 3, 3, seed=68).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    saved = hb.USE_WGRAD_TWO_PER_CU
+    try:
+        out = {}
+        for flag in (False, True):
+            hb.USE_WGRAD_TWO_PER_CU = flag
+            out[flag] = ops.conv_wgrad(dy, x, None, w, cfg, True)
+    finally:
+        hb.USE_WGRAD_TWO_PER_CU = saved
+    torch.testing.assert_close(out[True][0], out[False][0], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-4)
