@@ -22,21 +22,18 @@ def blur_fwhm_voxels(slice_thickness, target_thickness):
     return float(np.sqrt(slice_thickness ** 2 - target_thickness ** 2) / target_thickness)
 
 
+_TO_Z = {0: (2, 0, 1, 3), 1: (1, 2, 0, 3)}   # axis order that moves the low-resolution axis where the reference wants it
+
+
 def lr_axis_to_z(img, lr_axis):
+    """(ref :100-113) a trailing singleton fifth axis is squeezed away first."""
     if img.ndim == 5:
         img = np.squeeze(img)
-    if lr_axis == 0:
-        return img.transpose(2, 0, 1, 3)
-    if lr_axis == 1:
-        return img.transpose(1, 2, 0, 3)
-    return img
+    return img.transpose(_TO_Z[lr_axis]) if lr_axis in _TO_Z else img
 
 
 def z_axis_to_lr_axis(img, lr_axis):
+    """(ref :117-131) the reference applies the same permutation in this direction."""
     if img.ndim == 5:
         img = np.squeeze(img, axis=4)
-    if lr_axis == 0:
-        return img.transpose(2, 0, 1, 3)
-    if lr_axis == 1:
-        return img.transpose(1, 2, 0, 3)
-    return img
+    return img.transpose(_TO_Z[lr_axis]) if lr_axis in _TO_Z else img
