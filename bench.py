@@ -313,7 +313,7 @@ def main():
                     "ms_per_step": f["seconds"] / args.steps * 1e3,
                     "algorithmic_gflop_per_step": f["flops"] / args.steps / 1e9}
 
-        names = {"wino_conv": "wino_conv_big_kernel / wino_conv_w32_kernel / wino_conv_kernel / wino_flat_conv_kernel: "
+        names = {"wino_conv": "wino_conv_big8_kernel / wino_conv_w32_kernel / wino_conv_kernel / wino_flat_conv_kernel: "
                               "Winograd F(2x2,3x3)-over-(H,W) fp32 MFMA conv forward / input gradient",
                  "gather_gemm": "gather_gemm_kernel / halo_conv_kernel: fp32 MFMA implicit-GEMM conv (strided, 1x1x1, "
                                 "transposed phases)",
@@ -330,7 +330,8 @@ def main():
             # (profiles/r02_pmc_hbm_flavr.json: tools/pmc_hbm.py over three rocprofv3 passes of `bench.py --workload flavr`)
             tp = os.path.join(ROOT, "profiles", "r02_pmc_hbm_flavr.json")
             if args.workload == "flavr" and size == 128 and dominant == "wino_conv" and os.path.exists(tp):
-                k = json.load(open(tp)).get("kernels", {}).get("wino_conv_big_kernel", {})
+                ks = json.load(open(tp)).get("kernels", {})
+                k = ks.get("wino_conv_big8_kernel") or ks.get("wino_conv_big_kernel") or {}
                 if k.get("hbm_bytes_per_launch"):
                     r["traffic"] = k["hbm_bytes_per_launch"]
                     r["traffic_source"] = "profiles/r02_pmc_hbm_flavr.json (PMC FETCH_SIZE x2 + WRITE_SIZE per launch)"
