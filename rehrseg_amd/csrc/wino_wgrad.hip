@@ -26,6 +26,10 @@
 
 namespace {
 
+#ifndef WW_W8_REGION
+#define WW_W8_REGION 1   // 8-wave mode: keep the per-quarter scheduling regions (0: one region per k-group; measured below)
+#endif
+
 constexpr int RH = 4, RW = 16;           // outputs per staged region = 2 x 8 tiles
 constexpr int XH = RH + 2, XW = RW + 2;  // input patch
 constexpr int YV = RH * RW, XV = XH * XW;
@@ -37,6 +41,7 @@ struct WWParams {
   int a_tiles, c_tiles, Capad, Cgpad;
   int fa, fb;
   bool two;      // 64 x 32 blocks, two per CU
+  bool w8;       // 64 x 64 block of 8 waves (two wave sets)
   // narrow planes (Lw < 16, e.g. the 12x12 layers of the reference's 96x96 crops): G consecutive (sample, depth)
   // slices are laid side by side, each with a 1-column zero gutter on either side, into a virtual lattice of
   // width G*(Lw+2) -- a pure index map in the fetch; dY is zero in the gutters, so whatever the transform
@@ -49,39 +54,43 @@ struct WWParams {
 
 // FA / FB = 32-channel groups of dY / x per block (2 x 2: one block per CU with the full register
 // file; smaller shapes for 32-channel layers run several blocks per CU).
-template <int FA, int FB>
+// WS = wave sets per block: 1 (4 waves), or 2 (8 waves, two per SIMD: set ws owns the dY groups ws*FA .. ws*FA+FA-1 and
+// all FB x groups; both sets read the same staged region, so nothing is staged twice -- unlike two co-resident blocks)
+template <int FA, int FB, int WS = 1>
 struct WWCfg {
   // LDS holds both operands TRANSPOSED, [row][channel][column] with a 20-float column pitch: a lane
   // (= channel) reads its 8 / 10 consecutive columns as 128-bit words (5 groups of 4 banks between
   // neighbouring channels: conflict-free), 20 reads per k-group instead of 72 scalar ones
   static constexpr int WP = 20;
-  static constexpr int CA = FA * 32, CG = FB * 32;
+  static constexpr int CA = FA * WS * 32, CG = FB * 32;
   static constexpr int YBUF = RH * CA * WP, XBUF = XH * CG * WP, BUF = YBUF + XBUF;
   // staging pieces per thread: a wave instruction covers 16 columns x 4 channel quads of one (row, quad
   // group) -> 64 distinct banks for each of the 4 scalar stores of a piece
-  static constexpr int NPY = 2 * FA, NPXM = 3 * FB, NP = NPY + NPXM + 1;
+  static constexpr int NPY = 2 * FA, NPXM = 3 * FB / WS, NP = NPY + NPXM + 1;
+  static_assert((3 * FB) % WS == 0, "x patch pieces must divide over the waves");
   static constexpr int NPA = (NP + 1) / 2;
   static constexpr int NQ = FA * FB, NPREP = FA + FB;
-  static constexpr int MINB = (FA * FB == 4) ? 1 : ((FA * FB == 2) ? 1 : 2);
+  static constexpr int MINB = (WS == 2) ? 1 : ((FA * FB == 4) ? 1 : ((FA * FB == 2) ? 1 : 2));
 };
 
 // MINB_ = resident blocks per CU the register budget is cut for: the 64 x 32 shape also runs two blocks per CU (two
 // waves per SIMD, 256 registers each) for the 64 x 64-and-wider layers -- see plan()
-template <int FA, int FB, bool VIRT, int MINB_ = WWCfg<FA, FB>::MINB>
-__global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p) {
-  using C = WWCfg<FA, FB>;
+template <int FA, int FB, bool VIRT, int MINB_ = WWCfg<FA, FB>::MINB, int WS = 1>
+__global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWParams p) {
+  using C = WWCfg<FA, FB, WS>;
   constexpr int WP = C::WP, CA = C::CA, CG = C::CG, YBUF = C::YBUF, BUF = C::BUF;
   constexpr int NPY = C::NPY, NPXM = C::NPXM, NP = C::NP, NPA = C::NPA;
   const rehr_wgrad_desc& d = p.d;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = wv8 & 3, ws = wv8 >> 2;   // Winograd row, wave set
   const int half = lane >> 5, col = lane & 31;
   const int split = blockIdx.x;
   const int at = blockIdx.y / p.c_tiles, ct = blockIdx.y - at * p.c_tiles;
   const int jd = blockIdx.z;
-  const int ca0 = at * (FA * 32), cg0 = ct * (FB * 32);
+  const int ca0 = at * (FA * WS * 32), cg0 = ct * (FB * 32);
   const int it0 = split * p.items_per_split;
   const int it1 = min(it0 + p.items_per_split, p.items);
   const int nstages = it1 - it0;
@@ -93,7 +102,8 @@ __global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p
   const float s2 = (r == 1) ? 1.f : -1.f;
 
   // ---- staging pieces: lane = (column w16, quad ql) of the wave's (row, quad group) combo
-  const int wv = r;  // wave index doubles as the staging wave id
+  const int wv = wv8;  // the wave index is the staging wave id
+  constexpr int QY = 2 * FA * WS, QX = 2 * FB, WSTEP = 4 * WS;   // 16-channel groups per dY / x row; waves per block
   const int w16 = lane & 15, ql = lane >> 4;
   const int64_t l_img = (int64_t)d.Ld * d.Lh * d.Lw * d.ldl, g_img = (int64_t)d.Dg * d.Hg * d.Wg * d.ldg;
   const uint32_t l_bytes = (uint32_t)(l_img * 4), g_bytes = (uint32_t)(g_img * 4);
@@ -101,11 +111,11 @@ __global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p
   // piece i -> (kind, row, column, quad): 0 = dY tile, 1 = x patch
   auto piece = [&](const int i, int& kind, int& row, int& cw, int& q) {
     if (i < NPY) {
-      const int combo = wv + 4 * i;
-      kind = 0; row = combo / (2 * FA); q = (combo % (2 * FA)) * 4 + ql; cw = w16;
+      const int combo = wv + WSTEP * i;
+      kind = 0; row = combo / QY; q = (combo % QY) * 4 + ql; cw = w16;
     } else if (i < NPY + NPXM) {
-      const int combo = wv + 4 * (i - NPY);
-      kind = 1; row = combo / (2 * FB); q = (combo % (2 * FB)) * 4 + ql; cw = w16;
+      const int combo = wv + WSTEP * (i - NPY);
+      kind = 1; row = combo / QX; q = (combo % QX) * 4 + ql; cw = w16;
     } else {  // patch columns 16, 17: 6 rows x 2 columns x 8*FB quads on the first 96*FB threads
       const int rest = tid / (8 * FB);
       kind = (tid < 96 * FB) ? 1 : 2; row = rest >> 1; cw = 16 + (rest & 1); q = tid % (8 * FB);
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   struct Raw { f32x4 a0, a1, b0, b1; f32x2_ a2, b2; };  // the LDS words of one operand set, untransformed
   auto read_z = [&](int buf, const int g, const int fa, Raw& w) {
-    const float* y0 = ybase + buf + ((2 * g) * CA + fa * 32) * WP;
+    const float* y0 = ybase + buf + ((2 * g) * CA + (ws * FA + fa) * 32) * WP;
     const float* y1 = y0 + CA * WP;
     w.a0 = *reinterpret_cast<const f32x4*>(y0); w.a1 = *reinterpret_cast<const f32x4*>(y0 + 4);
     w.b0 = *reinterpret_cast<const f32x4*>(y1); w.b1 = *reinterpret_cast<const f32x4*>(y1 + 4);
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p
     Raw raw[2];
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
-      if ((s_ & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // one scheduling region per quarter (16 MFMAs)
+      if ((s_ & 3) == 0 && (WS == 1 || WW_W8_REGION)) __builtin_amdgcn_sched_barrier(0);  // one scheduling region per quarter (16 MFMAs)
 #pragma unroll
       for (int j = 0; j < NPREP; ++j) {
         if (s_ == (j + 1) * SPC) prep_xform(j, raw[j & 1], ZN, VN);
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p
       // empty anchor on the four accumulators: instruction selection may not let the MFMAs drift out of their
       // step (measured: -2 %; anchoring the transforms or the address arithmetic the same way measured worse).
       // The two-blocks-per-CU shape has a second wave to fill gaps and runs better without it.
-      if constexpr (C::MINB == 1)
+      if constexpr (C::MINB == 1 && WS == 1)
       asm volatile("" : "+a"(acc[qi / FB][qi % FB][0]), "+a"(acc[qi / FB][qi % FB][1]), "+a"(acc[qi / FB][qi % FB][2]),
                         "+a"(acc[qi / FB][qi % FB][3]));
     }
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p
 #pragma unroll
     for (int fa = 0; fa < FA; ++fa) {
       const float t = bsum[fa] + __shfl_xor(bsum[fa], 32, 64);
-      if (half == 0) p.slab_bias[(int64_t)split * p.Capad + ca0 + fa * 32 + col] = t;
+      if (half == 0) p.slab_bias[(int64_t)split * p.Capad + ca0 + (ws * FA + fa) * 32 + col] = t;
     }
   }
   // ---- store the tiles of this wave: slab[split][jd][r*4+c][co][ci], signs of the folded
@@ -397,7 +407,7 @@ __global__ __launch_bounds__(256, MINB_) void wino_wgrad_kernel(const WWParams p
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
-          sc[(int64_t)(ca0 + fa * 32 + row) * p.Cgpad + cg0 + fb * 32 + col] = sgn * acc[fa][fb][c][k];
+          sc[(int64_t)(ca0 + (ws * FA + fa) * 32 + row) * p.Cgpad + cg0 + fb * 32 + col] = sgn * acc[fa][fb][c][k];
         }
   }
 }
@@ -478,17 +488,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const WWParams p
   }
 }
 
-template <int FA, int FB, bool VIRT, int MINB_ = WWCfg<FA, FB>::MINB>
+template <int FA, int FB, bool VIRT, int MINB_ = WWCfg<FA, FB>::MINB, int WS = 1>
 int launch_ww(const WWParams& p, dim3 grid, hipStream_t stream) {
-  const size_t smem = ((size_t)2 * WWCfg<FA, FB>::BUF + 128) * sizeof(float);  // + the spare pad of stage()
+  const size_t smem = ((size_t)2 * WWCfg<FA, FB, WS>::BUF + 128) * sizeof(float);  // + the spare pad of stage()
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<FA, FB, VIRT, MINB_>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<FA, FB, VIRT, MINB_, WS>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return REHR_EHIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wino_wgrad_kernel<FA, FB, VIRT, MINB_>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((wino_wgrad_kernel<FA, FB, VIRT, MINB_, WS>), grid, dim3(256 * WS), smem, stream, p);
   return REHR_OK;
 }
 
@@ -539,6 +549,8 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   // issue gaps of the first; dY is then staged by both blocks of a pair
   p.two = (d.flags & REHR_WGRAD_TWO_PER_CU) && p.fa == 2 && p.fb == 2;
   if (p.two) p.fb = 1;
+  // REHR_WGRAD_8WAVE: the 64 x 64 block as two wave sets of 32 x 64 (8 waves, two per SIMD, one staged region)
+  p.w8 = !p.two && (d.flags & REHR_WGRAD_8WAVE) && p.fa == 2 && p.fb == 2;
   p.a_tiles = (d.Ca + p.fa * 32 - 1) / (p.fa * 32);
   p.c_tiles = (d.Cg + p.fb * 32 - 1) / (p.fb * 32);
   p.Capad = p.a_tiles * p.fa * 32;
@@ -596,7 +608,8 @@ int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
   dim3 grid(p.splits, p.a_tiles * p.c_tiles, d.td.count);
   int rc;
   const bool virt = p.G != 0;
-  if (p.fa == 2 && p.fb == 2) rc = virt ? launch_ww<2, 2, true>(p, grid, stream) : launch_ww<2, 2, false>(p, grid, stream);
+  if (p.w8) rc = virt ? launch_ww<1, 2, true, 1, 2>(p, grid, stream) : launch_ww<1, 2, false, 1, 2>(p, grid, stream);
+  else if (p.fa == 2 && p.fb == 2) rc = virt ? launch_ww<2, 2, true>(p, grid, stream) : launch_ww<2, 2, false>(p, grid, stream);
   else if (p.fa == 1 && p.fb == 1) rc = virt ? launch_ww<1, 1, true>(p, grid, stream) : launch_ww<1, 1, false>(p, grid, stream);
   else if (p.fa == 1) rc = virt ? launch_ww<1, 2, true>(p, grid, stream) : launch_ww<1, 2, false>(p, grid, stream);
   else if (p.two) rc = virt ? launch_ww<2, 1, true, 2>(p, grid, stream) : launch_ww<2, 1, false, 2>(p, grid, stream);

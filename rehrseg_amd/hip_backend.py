@@ -152,6 +152,7 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
 USE_WINOGRAD = True
 USE_WINOGRAD_WGRAD = True
 USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps
+USE_WGRAD_8WAVE = True   # Winograd weight gradient: the 64 x 64 block as 8 waves (two per SIMD)
 USE_WGRAD_TWO_PER_CU = False  # Winograd weight gradient: two 64 x 32 blocks per CU for the >= 64-channel layers
 USE_W32_TWO_PER_CU = False # fp32 32-channel-tile Winograd kernel: two 512-thread blocks per CU (False: one of 1024)
 USE_WINO_8WAVE = True   # fp32 big-tile Winograd kernel: two waves per SIMD (wino_conv_big8_kernel)
@@ -278,7 +279,8 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     d.dst_sa, d.dst_sc, d.dst_st = dst_strides
     d.accumulate = int(accumulate)
     d.dbias = _ptr(dbias)
-    d.flags = (0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT) | (L.WGRAD_TWO_PER_CU if USE_WGRAD_TWO_PER_CU else 0)
+    d.flags = ((0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT) | (L.WGRAD_TWO_PER_CU if USE_WGRAD_TWO_PER_CU else 0) |
+               (L.WGRAD_8WAVE if USE_WGRAD_8WAVE else 0))
     lib = L.load()
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
     if bf16:

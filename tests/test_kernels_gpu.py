@@ -481,3 +481,23 @@ def test_winograd_wgrad_two_per_cu_variant():
         hb.USE_WGRAD_TWO_PER_CU = saved
     torch.testing.assert_close(out[True][0], out[False][0], rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-4)
+
+
+def test_winograd_wgrad_eight_wave_variant():
+    """REHR_WGRAD_8WAVE (the 64 x 64 block as two wave sets, two waves per SIMD) against the four-wave block: the same
+    products in the same order per accumulator -> the same bits."""
+    from rehrseg_amd import hip_backend as hb
+    x = _mk(2, 64, 4, 32, 48, seed=71).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    dy = _mk(2, 128, 4, 32, 48, seed=72).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = _mk(128, 64, 3, 3, 3, seed=73).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    saved = hb.USE_WGRAD_8WAVE
+    try:
+        out = {}
+        for flag in (False, True):
+            hb.USE_WGRAD_8WAVE = flag
+            out[flag] = ops.conv_wgrad(dy, x, None, w, cfg, True)
+    finally:
+        hb.USE_WGRAD_8WAVE = saved
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
