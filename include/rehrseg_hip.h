@@ -109,6 +109,8 @@ typedef struct {
 
 /* fp32 entry points: the eight-wave organisation of the big-tile Winograd kernel (two waves per SIMD) */
 #define REHR_GG_WINO_8WAVE 4
+/* bf16 entry points: the LDS halo-brick kernel with eight waves per block (two per SIMD) instead of four */
+#define REHR_GG_HALO_8WAVE 16
 /* fp32 entry points: the 32-channel-tile Winograd kernel with one 1024-thread block per CU instead of two 512-thread ones */
 #define REHR_GG_W32_ONE_PER_CU 8
 

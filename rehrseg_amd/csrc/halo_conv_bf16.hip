@@ -34,8 +34,11 @@ constexpr int BK = 32;              // channels per chunk
 constexpr int XROW = BK * 2 + 16;   // halo row stride in bytes (padded)
 constexpr int WROW = BK * 2;        // weight row (one output channel of one tap) in bytes, pieces swizzled
 constexpr int TPR = 4;              // threads per halo row (16 bytes each)
-constexpr int RPP = 256 / TPR;      // halo rows per staging pass
-constexpr int FM = 4;               // 32-voxel tiles per wave
+// NWV = waves per block: 4 (one per SIMD, 128 voxels = 4 tiles each) or 8 (two per SIMD, 64 voxels = 2 tiles each:
+// a second resident wave fills the issue gaps of the first, at the price of one weight-fragment read per 2 MFMAs)
+template <int NWV> struct HBW {
+  static constexpr int NTHR = 64 * NWV, RPP = NTHR / TPR, FM = 16 / NWV;
+};
 constexpr int BVOX = 512;
 constexpr int BN = 32;
 constexpr int MAXTAPS = 27;
@@ -52,9 +55,10 @@ struct HBParams {
 };
 
 // NT3 = taps / 3 (9: 3x3x3, 3: 1x3x3): the sweep is fully unrolled so that the next halo's loads can be spread over it
-template <int BD, int BH, int BW, int NT3>
-__global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p) {
+template <int BD, int BH, int BW, int NT3, int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void halo_conv_bf16_kernel(const HBParams p) {
   static_assert(BD * BH * BW == BVOX, "512 voxels");
+  constexpr int NTHR = HBW<NWV>::NTHR, RPP = HBW<NWV>::RPP, FM = HBW<NWV>::FM;
   constexpr int MAXX = ((BD + 2) * (BH + 2) * (BW + 2) + RPP - 1) / RPP;
   const rehr_gather_gemm_desc& d = p.d;
 
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
   int arow[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int r = wave * 128 + i * 32 + vtile;
+    const int r = wave * (FM * 32) + i * 32 + vtile;
     const int rd = r / (BH * BW), rh = (r / BW) % BH, rw = r % BW;
     arow[i] = ((rd * p.HH + rh) * p.HW + rw) * XROW + 16 * half;
   }
@@ -167,13 +171,13 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
       const_cast<__bf16*>(reinterpret_cast<const __bf16*>(d.wp)), 0, p.wp_bytes, 0x00020000);
   auto stage_weights = [&](int cc) {
     constexpr int NPC = ntaps * BN * 4;            // 16-byte pieces
-    constexpr int PPT = (NPC + 255) / 256;         // per thread: 14 (27 taps) / 5 (9 taps)
+    constexpr int PPT = (NPC + NTHR - 1) / NTHR;   // per thread (4 waves): 14 (27 taps) / 5 (9 taps)
     const int thw = d.th.count * d.tw.count;
     u32x4 v[PPT];
     int dst[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {                // every load in flight before the first LDS write
-      const int pc = u * 256 + tid;
+      const int pc = u * NTHR + tid;
       const int t = pc >> 7, co = (pc >> 2) & 31, c = pc & 3;
       const int jd = t / thw, jr = t - jd * thw, jh = jr / d.tw.count, jw = jr - jh * d.tw.count;
       const int wt = ((d.td.k0 + d.td.ks * jd) * d.KH + (d.th.k0 + d.th.ks * jh)) * d.KW + (d.tw.k0 + d.tw.ks * jw);
@@ -219,11 +223,11 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
   // (Per-wave atomics from single lanes -- 256 per block onto the same few cache lines -- serialised at the memory
   // side: 5 ms for a 1x32x160^3 layer.)  Block-uniform: every thread calls it.
   auto flush_stats = [&](int sn) {
-    float* red = reinterpret_cast<float*>(Xs);   // [32 values][256 threads]
+    float* red = reinterpret_cast<float*>(Xs);   // [32 values][NTHR threads]
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      red[k * 256 + tid] = s1[k];
-      red[(16 + k) * 256 + tid] = s2[k];
+      red[k * NTHR + tid] = s1[k];
+      red[(16 + k) * NTHR + tid] = s2[k];
       s1[k] = s2[k] = 0.f;
     }
     __syncthreads();
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
       const int k = 4 * (c >> 3) + (c & 3) + 16 * st, h = (c >> 2) & 1;
       float sum = 0.f;
 #pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4)
-        for (int l = 0; l < 32; ++l) sum += red[k * 256 + w4 * 64 + h * 32 + l];
+      for (int w4 = 0; w4 < NWV; ++w4)
+        for (int l = 0; l < 32; ++l) sum += red[k * NTHR + w4 * 64 + h * 32 + l];
       if (n0 + c < d.Cout && (st == 0 || d.stats_mode == 2))
         atomicAdd(d.stats + ((int64_t)sn * d.Cout + n0 + c) * 2 + st, (double)sum);
     }
@@ -294,10 +298,10 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
         for (int i = 0; i < FM; ++i)
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set], fx[set][i], acc[i], 0, 0, 0);
       };
-#define HB_PIN()                                                        \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */        \
-  __builtin_amdgcn_sched_group_barrier(0x100, 5, 0); /* 5 DS reads */    \
-  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); /* 3 MFMA */        \
+#define HB_PIN()                                                                    \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* 1 MFMA */                \
+  __builtin_amdgcn_sched_group_barrier(0x100, FM + 1, 0); /* the step's DS reads */   \
+  __builtin_amdgcn_sched_group_barrier(0x008, FM - 1, 0); /* the other MFMAs */       \
   __builtin_amdgcn_sched_barrier(0)
       tap_base(0, 0);
       rd(0, 0, 0, 0);          // step 0 = (tap 0, kk 0)
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
       const int bw_ = tr % p.nb_w; tr /= p.nb_w;
       const int bh_ = tr % p.nb_h;
       const int bd_ = tr / p.nb_h;
-      for (int v = tid; v < BVOX; v += 256) {
+      for (int v = tid; v < BVOX; v += NTHR) {
         const int od = bd_ * BD + v / (BH * BW), oh = bh_ * BH + (v / BW) % BH, ow = bw_ * BW + v % BW;
         int off = -1;
         if (od < d.Ld && oh < d.Lh && ow < d.Lw)
@@ -365,11 +369,11 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
         // bf16 output through a wave-private LDS image [128 voxels][32 channels] (80-byte rows): the accumulator
         // layout (a voxel per lane, 4 channels per register quad) would store 8-byte pieces of 32 different rows
         // per instruction; from the image every lane stores 16 bytes and 4 lanes complete a voxel's 64-byte segment.
-        unsigned char* img = Xs + wave * (128 * XROW);
+        unsigned char* img = Xs + wave * (FM * 32 * XROW);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           float lv = 0.f;   // 1 for a voxel inside the lattice: the statistics skip padding voxels
-          if (want_stats) lv = row_out[wave * 128 + i * 32 + vtile] >= 0 ? 1.f : 0.f;
+          if (want_stats) lv = row_out[wave * (FM * 32) + i * 32 + vtile] >= 0 ? 1.f : 0.f;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float v[4];
@@ -396,16 +400,16 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const HBParams p
         const bool pok = (n0 + 8 * piece + 7) < d.Cout;
         const uint32_t cby = (uint32_t)(n0 + 8 * piece) * 2u, ldyb = (uint32_t)d.ldy * 2u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {        // 8 stores of 16 voxels x 64 bytes
+        for (int j = 0; j < 2 * FM; ++j) {   // stores of 16 voxels x 64 bytes
           const int row = j * 16 + vv;
-          const int off = row_out[wave * 128 + row];
+          const int off = row_out[wave * (FM * 32) + row];
           const u32x4 val = *reinterpret_cast<const u32x4*>(img + row * XROW + piece * 16);
           __builtin_amdgcn_raw_buffer_store_b128(val, rsy, (off >= 0 && pok) ? (uint32_t)off * ldyb + cby : y_bytes, 0, 0);
         }
       } else {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-          const int off = row_out[wave * 128 + i * 32 + vtile];
+          const int off = row_out[wave * (FM * 32) + i * 32 + vtile];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int col = n0 + 8 * g + 4 * half;
@@ -459,8 +463,9 @@ void span(const rehr_axis_taps& t, int b, int* mn, int* mx) {
   *mx = hi;
 }
 
-template <int BD, int BH, int BW, int NT3>
+template <int BD, int BH, int BW, int NT3, int NWV>
 int launch(HBParams p, hipStream_t stream) {
+  constexpr int RPP = HBW<NWV>::RPP;
   const rehr_gather_gemm_desc& d = p.d;
   if (d.Ld < (BD + 1) / 2 || d.Lh < BH || d.Lw < BW) return REHR_ENOSUP;
   const int64_t nb_d = (d.Ld + BD - 1) / BD, nb_h = (d.Lh + BH - 1) / BH, nb_w = (d.Lw + BW - 1) / BW;
@@ -483,7 +488,7 @@ int launch(HBParams p, hipStream_t stream) {
   if (want < 1) want = 1;
   if (want > p.ntiles) want = p.ntiles;
   p.tiles_per_block = (int)((p.ntiles + want - 1) / want);
-  auto kern = halo_conv_bf16_kernel<BD, BH, BW, NT3>;
+  auto kern = halo_conv_bf16_kernel<BD, BH, BW, NT3, NWV>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -492,7 +497,7 @@ int launch(HBParams p, hipStream_t stream) {
     attr_set = true;
   }
   const int64_t blocks_x = (p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_x, n_tiles, 1), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks_x, n_tiles, 1), dim3(64 * NWV), smem, stream, p);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -529,13 +534,24 @@ int halo_conv_bf16_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   }
   // brick shapes in order of preference; one that pads the lattice by more than 1.3x (or does not fit it) declines
   int rc;
+  if (d.flags & REHR_GG_HALO_8WAVE) {
+    if (T == 27) {
+      rc = launch<4, 8, 16, 9, 8>(p, stream);
+      if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 9, 8>(p, stream);
+    } else {
+      rc = launch<4, 8, 16, 3, 8>(p, stream);
+      if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 3, 8>(p, stream);
+      if (rc == REHR_ENOSUP) rc = launch<2, 16, 16, 3, 8>(p, stream);
+    }
+    return rc;
+  }
   if (T == 27) {
-    rc = launch<4, 8, 16, 9>(p, stream);
-    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 9>(p, stream);
+    rc = launch<4, 8, 16, 9, 4>(p, stream);
+    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 9, 4>(p, stream);
   } else {
-    rc = launch<4, 8, 16, 3>(p, stream);
-    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 3>(p, stream);
-    if (rc == REHR_ENOSUP) rc = launch<2, 16, 16, 3>(p, stream);
+    rc = launch<4, 8, 16, 3, 4>(p, stream);
+    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 3, 4>(p, stream);
+    if (rc == REHR_ENOSUP) rc = launch<2, 16, 16, 3, 4>(p, stream);
   }
   return rc;
 }

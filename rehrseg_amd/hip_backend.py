@@ -152,6 +152,7 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
 USE_WINOGRAD = True
 USE_WINOGRAD_WGRAD = True
 USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps
+USE_HALO_8WAVE = True   # mixed precision: the halo-brick kernel with eight waves per block
 USE_WGRAD_8WAVE = True   # Winograd weight gradient: the 64 x 64 block as 8 waves (two per SIMD)
 USE_WGRAD_TWO_PER_CU = False  # Winograd weight gradient: two 64 x 32 blocks per CU for the >= 64-channel layers
 USE_W32_TWO_PER_CU = False # fp32 32-channel-tile Winograd kernel: two 512-thread blocks per CU (False: one of 1024)
@@ -191,7 +192,8 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             raise L.RehrsegHipError("mixed-precision gather-GEMM: x1, x2 and the packed weights must all be bfloat16")
         if bias is not None and bias.dtype != torch.float32:
             raise L.RehrsegHipError("bias stays float32")
-        d.flags = (L.GG_Y_F32 if y.dtype == torch.float32 else 0) | (0 if USE_HALO_BF16 else L.GG_NO_HALO)
+        d.flags = ((L.GG_Y_F32 if y.dtype == torch.float32 else 0) | (0 if USE_HALO_BF16 else L.GG_NO_HALO) |
+                   (L.GG_HALO_8WAVE if USE_HALO_8WAVE else 0))
     elif wp.dtype != torch.float32 or y.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
         raise L.RehrsegHipError("fp32 gather-GEMM: every operand must be float32")
     elif USE_WINOGRAD and tile[0] >= 0:

@@ -23,6 +23,7 @@ GG_Y_F32 = 1      # rehr_gather_gemm_desc.flags
 GG_NO_HALO = 2
 GG_WINO_8WAVE = 4
 GG_W32_ONE_PER_CU = 8
+GG_HALO_8WAVE = 16
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p
