@@ -190,6 +190,8 @@ typedef struct {
 #define REHR_WGRAD_TWO_PER_CU 2
 /* the 64 x 64 block of the Winograd weight gradient as 8 waves (two per SIMD) instead of 4 */
 #define REHR_WGRAD_8WAVE 4
+/* bf16 weight gradient: the LDS brick kernel with eight waves per block (two per SIMD) instead of four */
+#define REHR_WGRAD_BRICK_8WAVE 8
 
 /* Mixed-precision weight gradient: l and g point at bf16 elements (ld* in elements, % 8 == 0; Ca, Cg % 8 == 0),
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 slabs and fp32 dst (the master-weight gradient).  dbias must

@@ -30,13 +30,18 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int BD = 4, BH = 8, BW = 16, BVOX = BD * BH * BW;   // brick
 constexpr int ROW = 64;                                       // bytes per voxel row of an LDS image (32 bf16)
-constexpr int RPP = 64;                                       // rows staged per pass (4 threads x 16 B per row)
-constexpr int LPASS = BVOX / RPP;                             // 8 passes for the L brick
-constexpr int MAXW = 7;                                       // taps per wave (27 taps / 4 waves)
+// NWV = waves per block: 4 (one per SIMD, <= 7 taps each) or 8 (two per SIMD, <= 4 taps each: the second resident wave
+// fills the issue gaps of the first; the L fragment of a k step then serves 3-4 MFMAs instead of 6-7)
+template <int NWV> struct WBW {
+  static constexpr int RPP = 16 * NWV;                        // rows staged per pass (4 threads x 16 B per row)
+  static constexpr int LPASS = BVOX / RPP;                    // passes for the L brick
+  static constexpr int MAXW = (27 + NWV - 1) / NWV;           // taps per wave
+};
 
 // KD = taps along depth (3 or 1); HD/HH/HW = halo extents
-template <int KD>
-__global__ __launch_bounds__(256, 1) void wgrad_brick_bf16_kernel(const WGParams p, const BrickBf16 g) {
+template <int KD, int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void wgrad_brick_bf16_kernel(const WGParams p, const BrickBf16 g) {
+  constexpr int RPP = WBW<NWV>::RPP, LPASS = WBW<NWV>::LPASS, MAXW = WBW<NWV>::MAXW;
   constexpr int HD = BD + KD - 1, HH = BH + 2, HW = BW + 2, HVOX = HD * HH * HW;
   constexpr int GPASS = (HVOX + RPP - 1) / RPP;                // 17 (KD 3) / 12 (KD 1)
   constexpr int NT = KD * 9;
@@ -85,12 +90,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_brick_bf16_kernel(const WGParams
   const int lane_row = 8 * hk + qq;                          // voxel row inside a 16-voxel k step
   const int lane_col = (16 * cg + 4 * pp) * 2;               // byte offset of the lane's 4 channels
 
-  // this wave's taps: t = wave + 4 j; per-lane LDS base of each (the halo offset of the tap + the lane's row / column)
+  // this wave's taps: t = wave + NWV j; per-lane LDS base of each (the halo offset of the tap + the lane's row / column)
   int gbase[MAXW];
   int ntw = 0;
 #pragma unroll
   for (int j = 0; j < MAXW; ++j) {
-    const int t = wave + 4 * j;
+    const int t = wave + NWV * j;
     const bool on = t < NT;
     const int tt = on ? t : 0;
     const int jd = tt / 9, jh = (tt / 3) % 3, jw = tt % 3;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_brick_bf16_kernel(const WGParams
   float* slab = d.workspace + ((int64_t)blockIdx.x * p.T) * p.Capad * p.Cgpad;
 #pragma unroll
   for (int j = 0; j < MAXW; ++j) {
-    const int t = wave + 4 * j;
+    const int t = wave + NWV * j;
     if (t < NT) {
       float* o = slab + ((int64_t)t * p.Capad + a0) * p.Cgpad + c0 + (lane & 31);
 #pragma unroll
@@ -254,31 +259,28 @@ bool wgrad_brick_bf16_plan(const rehr_wgrad_desc& d, WGParams& w, BrickBf16& o) 
   return true;
 }
 
-int wgrad_brick_bf16_launch(const WGParams& w, const BrickBf16& o, hipStream_t stream) {
-  const int KD = w.d.td.count;
+template <int KD, int NWV>
+static int wgrad_brick_bf16_launch_t(const WGParams& w, const BrickBf16& o, hipStream_t stream) {
+  constexpr int RPP = WBW<NWV>::RPP;
   const int hvox = (BD + KD - 1) * (BH + 2) * (BW + 2);
   const size_t smem = (size_t)((hvox + RPP - 1) / RPP) * RPP * ROW + (size_t)BVOX * ROW;
   const dim3 grid(w.splits, w.a_tiles * w.c_tiles, 1);
-  static bool set3 = false, set1 = false;
-  if (KD == 3) {
-    auto kern = wgrad_brick_bf16_kernel<3>;
-    if (!set3) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) !=
-          hipSuccess)
-        return REHR_EHIP;
-      set3 = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, w, o);
-  } else {
-    auto kern = wgrad_brick_bf16_kernel<1>;
-    if (!set1) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) !=
-          hipSuccess)
-        return REHR_EHIP;
-      set1 = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, w, o);
+  auto kern = wgrad_brick_bf16_kernel<KD, NWV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) !=
+        hipSuccess)
+      return REHR_EHIP;
+    attr_set = true;
   }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), smem, stream, w, o);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
+}
+
+int wgrad_brick_bf16_launch(const WGParams& w, const BrickBf16& o, hipStream_t stream) {
+  const bool w8 = (w.d.flags & REHR_WGRAD_BRICK_8WAVE) != 0;
+  if (w.d.td.count == 3)
+    return w8 ? wgrad_brick_bf16_launch_t<3, 8>(w, o, stream) : wgrad_brick_bf16_launch_t<3, 4>(w, o, stream);
+  return w8 ? wgrad_brick_bf16_launch_t<1, 8>(w, o, stream) : wgrad_brick_bf16_launch_t<1, 4>(w, o, stream);
 }
