@@ -833,17 +833,20 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
   // half step = (k-group kk, channel group fn) = 16 MFMAs; behind them: the weights this half step has just released
   // are re-loaded for the next k-group, the A fragments of the next k-group are read and combined, the next item's
   // patch is fetched (kk 0, 2) and staged (kk 1, 3)
+#ifndef BIG8_FENCE
+#define BIG8_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #define BIG8_KGROUP(kk, vcur, vnext, NEXT_T, NEXT_KK, READS, EXTRA0, EXTRA1)  \
-  __builtin_amdgcn_sched_barrier(0);                                          \
+  BIG8_FENCE();                                                               \
   READS;                                                                      \
   EXTRA0;                                                                     \
   mfmas(0, vcur, u0);                                                         \
-  __builtin_amdgcn_sched_barrier(0);                                          \
+  BIG8_FENCE();                                                               \
   load_u(NEXT_T, NEXT_KK, 0, u0);                                             \
   EXTRA1;                                                                     \
   mfmas(1, vcur, u1);                                                         \
   combine(vnext);                                                             \
-  __builtin_amdgcn_sched_barrier(0);                                          \
+  BIG8_FENCE();                                                               \
   load_u(NEXT_T, NEXT_KK, 1, u1);
 
   for (int it = 0; it < items; ++it) {
