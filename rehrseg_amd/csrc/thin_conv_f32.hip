@@ -349,10 +349,12 @@ struct ThinF32WgradParams {
   int dseg, nseg, nstrip;
 };
 
+// 2 NW waves: wave = (32-voxel chunk c of the row, row pair rp); the four x rows of a plane step are independent in this
+// loop (every row reads its own A and B fragments), so the split costs nothing and gives every SIMD a second wave
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32WgradParams p) {
+__global__ __launch_bounds__(128 * NW) void thinf_wgrad_kernel(const ThinF32WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int W = NW * 32, NTHR = 64 * NW;
+  constexpr int W = NW * 32, NTHR = 128 * NW;
   constexpr int XROWB = (W + 4) * 64;                 // x row: 16 channels x 4 B per voxel, 2 zero voxels either side
   constexpr int XBUF = TF_BH * XROWB;
   constexpr int DROWB = W * 4 + 16;                   // one (row, co) line of dY
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
   unsigned char* xs = smem;                           // [2][4 rows][W + 4][16]
   unsigned char* ds = smem + 2 * XBUF;                // [6][8 rows][2 co][W (+4)]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int c = __builtin_amdgcn_readfirstlane(tid >> 6);   // 32-voxel chunk of the row
+  const int wv2 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = wv2 % NW, rp = wv2 / NW;                    // 32-voxel chunk of the row, row pair
   int b = blockIdx.x;
   const int seg = b % p.nseg; b /= p.nseg;
   const int strip = b % p.nstrip;
@@ -374,39 +377,39 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
     *reinterpret_cast<u32x4*>(xs + row * XROWB + vox * 64 + q4 * 16) = u32x4{0u, 0u, 0u, 0u};
   }
 
-  // x staging: 4 rows x W voxels x 4 quads = 8 pieces of 16 bytes per thread
+  // x staging: 4 rows x W voxels x 4 quads = 4 pieces of 16 bytes per thread
   const uint32_t img_bytes = (uint32_t)p.D * p.H * p.W * p.ldx * 4u;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x) + (int64_t)n_img * p.D * p.H * p.W * p.ldx, 0, img_bytes, 0x00020000);
   const uint32_t dplane = (uint32_t)p.H * p.W * p.ldx * 4u;
-  uint32_t xoff[8];
-  int xlds[8];
+  uint32_t xoff[4];
+  int xlds[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int piece = tid + NTHR * i;
     const int q4 = piece & 3, w = (piece >> 2) % W, row = (piece >> 2) / W;
     const int ih = h0 + row;
     xoff[i] = (ih < p.H) ? ((uint32_t)(ih * p.W + w) * p.ldx + q4 * 4) * 4u : img_bytes;
     xlds[i] = row * XROWB + (w + 2) * 64 + q4 * 16;
   }
-  u32x4 rxx[8];
+  u32x4 rxx[4];
   auto fetch_x = [&](int dp) {
     const bool dok = (unsigned)dp < (unsigned)p.D;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
       rxx[i] = __builtin_amdgcn_raw_buffer_load_b128(
           rs, (dok && xoff[i] != img_bytes) ? (uint32_t)dp * dplane + xoff[i] : img_bytes, 0, 0);
   };
   auto stage_x = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(xs + buf * XBUF + xlds[i]) = rxx[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(xs + buf * XBUF + xlds[i]) = rxx[i];
   };
-  // dY staging: 8 rows x W voxels, 4 voxels per thread
+  // dY staging: 8 rows x W voxels, 2 voxels per thread
   const float* dyn = p.dy + (int64_t)n_img * p.D * p.H * p.W * p.ldy;
-  int yvox[4], ylds[4];
-  bool yown[4];
+  int yvox[2], ylds[2];
+  bool yown[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const int v = tid + NTHR * i;
     const int w = v % W, row = v / W;
     const int ih = h0 - 2 + row;
@@ -414,13 +417,13 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
     ylds[i] = row * 2 * DROWB + w * 4;
     yown[i] = (row >= 2) & (row < 2 + TF_BH);
   }
-  float2 ry[4];
+  float2 ry[2];
   float db0 = 0.f, db1 = 0.f;
   auto fetch_y = [&](int dp) {
     const bool dok = (unsigned)dp < (unsigned)p.D;
     const bool down = (dp >= d0) & (dp < d1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       ry[i] = make_float2(0.f, 0.f);
       if (dok && yvox[i] >= 0) {
         const float* q = dyn + ((int64_t)dp * p.H * p.W + yvox[i]) * p.ldy;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
   };
   auto stage_y = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<float*>(ds + slot * DPLANE + ylds[i]) = ry[i].x;
       *reinterpret_cast<float*>(ds + slot * DPLANE + ylds[i] + DROWB) = ry[i].y;
     }
@@ -464,7 +467,8 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
     fetch_y(dx + 3);
     const unsigned char* xb = xs + buf * XBUF;
 #pragma unroll
-    for (int r = 0; r < TF_BH; ++r) {
+    for (int r2 = 0; r2 < TF_BH / 2; ++r2) {
+      const int r = rp * (TF_BH / 2) + r2;
 #pragma unroll 2
       for (int j = 0; j < 8; ++j) {
         float a[TF_K];
@@ -502,12 +506,12 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
   {
     db0 = wave_sum(db0);
     db1 = wave_sum(db1);
-    if (lane == 0) { red[c * 2] = db0; red[c * 2 + 1] = db1; }
+    if (lane == 0) { red[wv2 * 2] = db0; red[wv2 * 2 + 1] = db1; }
     __syncthreads();
     if (tid < 2) {
       float sdb = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < NW; ++w2) sdb += red[w2 * 2 + tid];
+      for (int w2 = 0; w2 < 2 * NW; ++w2) sdb += red[w2 * 2 + tid];
       slab[TF_SLAB + tid] = sdb;
     }
     __syncthreads();
@@ -515,12 +519,12 @@ __global__ __launch_bounds__(64 * NW) void thinf_wgrad_kernel(const ThinF32Wgrad
 #pragma unroll
   for (int t = 0; t < 25; ++t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[(c * 16 + 4 * kq + i) * 16 + mm] = acc[t][i];
+    for (int i = 0; i < 4; ++i) red[(wv2 * 16 + 4 * kq + i) * 16 + mm] = acc[t][i];
     __syncthreads();
     for (int e = tid; e < 256; e += NTHR) {
       float s = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < NW; ++w2) s += red[w2 * 256 + e];
+      for (int w2 = 0; w2 < 2 * NW; ++w2) s += red[w2 * 256 + e];
       slab[t * 256 + e] = s;
     }
     __syncthreads();
@@ -608,7 +612,7 @@ extern "C" int rehr_conv5_thin_f32_supported(const rehr_direct_conv_desc* d) {
     hipLaunchKernelGGL(KERNEL<NT_>, dim3((unsigned)blocks), dim3(THREADS), smem, st, p);                            \
   } while (0)
 #define TF_T512(n) 512
-#define TF_T64N(n) (64 * (n))
+#define TF_T64N(n) (128 * (n))
 
 extern "C" int rehr_conv5_thin_fwd_f32(const rehr_direct_conv_desc* dp, void* workspace, int64_t workspace_bytes,
                                        void* stream) {
