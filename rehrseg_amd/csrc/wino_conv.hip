@@ -731,7 +731,7 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
   auto advance = [&](Item& t) {
     if (++t.jd > jd_hi) { t.jd = jd_lo; ++t.chunk; }
   };
-  auto fetch = [&](const Item& t, const int lo) {   // pieces lo .. lo + NXH - 1
+  auto fetch_to = [&](f32x4 (&rx)[NXH], const Item& t, const int lo) {   // pieces lo .. lo + NXH - 1
     const bool live = (t.chunk < p.kchunks) & (items > 0);
     const int jd = t.jd;
     const int cc = (live ? t.chunk : 0) * 32;
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
       rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
     }
   };
-  auto stage = [&](int buf, const int lo) {
+  auto stage_from = [&](const f32x4 (&rx)[NXH], int buf, const int lo) {
 #pragma unroll
     for (int i = 0; i < NXH; ++i) {
       const int piece = tid + 512 * (lo + i);
@@ -760,6 +760,8 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
       if (piece < PVOX2 * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LDX + row * 8 + pq * 4) = rx[i];
     }
   };
+  auto fetch = [&](const Item& t, const int lo) { fetch_to(rx, t, lo); };
+  auto stage = [&](int buf, const int lo) { stage_from(rx, buf, lo); };
 
   const __amdgpu_buffer_rsrc_t rsu =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(up), 0, up_bytes, 0x00020000);
@@ -820,12 +822,16 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
   VFrag VA, VB;
   f32x4 u0[4], u1[4];   // weights of channel group 0 / 1 of the current k-group
   Item ci = {0, min(jd_lo, td.count - 1)}, ni = ci;
-  fetch(ci, 0);
-  stage(0, 0);
-  fetch(ci, NXH);
-  load_u(ci, 0, 0, u0);
+  {  // item 0: both halves of the patch in flight at once (u1's registers are free here): one memory round trip
+    static_assert(NXH <= 4, "the second half borrows u1");
+    f32x4 (&rx2)[NXH] = reinterpret_cast<f32x4 (&)[NXH]>(u1);
+    fetch(ci, 0);
+    fetch_to(rx2, ci, NXH);
+    load_u(ci, 0, 0, u0);
+    stage(0, 0);
+    stage_from(rx2, 0, NXH);
+  }
   load_u(ci, 0, 1, u1);
-  stage(0, NXH);
   __syncthreads();
   issue_reads(0, 0);
   combine(VA);
