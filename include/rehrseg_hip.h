@@ -351,6 +351,22 @@ int rehr_cosdist_stats_f32(const float* x1, const float* x2, double* stats, int3
 int rehr_cosdist_bwd_f32(const float* x1, const float* x2, const double* stats, float* dx1,
                          int32_t N, int64_t S, int32_t C, float scale, void* stream);
 
+/* UASR head of UNet_3D_3D(use_uncertainty=True) (reference models/FLAVR/FLAVR_arch.py:203-246): per output voxel the
+ * K candidate (image, segmentation) pairs are blended with softmax weights, and the weights give the uncertainty:
+ *   s = softmax_i ue_i;  out0 = sum_i s_i (tanh(om_2i) + 1)/2;  out1 = sum_i s_i om_{2i+1};
+ *   unc = sigmoid(bu + sum_i s_i wu_i)                      (uncertainty_out = Conv3d(K, 1, 1), :151,245)
+ * om [n][hw][d*2K + c], ue [n][hw][d*K + i]: the NDHWC outputs of feature_fuse1 / uncertainty_early on the fused
+ * slice (the split(dim=1) + stack(dim=2) of :205-211 is this indexing); out (N,2,D,H,W) and unc (N,1,D,H,W) NCDHW.
+ * K in {4, 8, 16, 32}; om, ue (dom, due) 16-byte aligned.
+ * bwd: dom, due from (gout, gunc) with the softmax recomputed; partial[blocks][K+1] (double) holds per-block sums of
+ * (dwu[0..K), dbu) -- blocks = rehr_uasr_mix_blocks(N, D, HW); the host adds them.                       */
+int32_t rehr_uasr_mix_blocks(int32_t N, int32_t D, int64_t HW);
+int rehr_uasr_mix_fwd_f32(const float* om, const float* ue, const float* wu, const float* bu, float* out,
+                          float* unc, int32_t N, int32_t K, int32_t D, int64_t HW, void* stream);
+int rehr_uasr_mix_bwd_f32(const float* om, const float* ue, const float* wu, const float* bu,
+                          const float* gout, const float* gunc, float* dom, float* due, double* partial,
+                          int32_t N, int32_t K, int32_t D, int64_t HW, void* stream);
+
 /* Max-pool of every (sample, depth) slice with a (H/2, W/2) window and stride: the 2x2 summary per slice and
  * channel that Distiller's structure loss compares (CriterionPairWiseforWholeFeatAfterPool,
  * models/seg_model.py:95-113; MaxPool2d(ceil_mode=True) with even H, W).  x [slices][H][W][C] (NDHWC slices),

@@ -59,6 +59,20 @@ def _dec_up(sd, i, x):
     return se_gating(y, sd[p + "1.attn_layer.0.weight"], sd[p + "1.attn_layer.0.bias"])
 
 
+def uasr_head(out, ue, w_unc, b_unc, n_outputs):
+    """FLAVR_arch.py:205-227, :244-246 from the two 1x1 responses (N, C, H, W) on the fused slice: candidate loop over
+    the softmax weights, then uncertainty_out + sigmoid."""
+    out = torch.stack(torch.split(out, out.shape[1] // n_outputs, dim=1), dim=2)
+    ue = torch.stack(torch.split(ue, ue.shape[1] // n_outputs, dim=1), dim=2)
+    sm = torch.softmax(ue, dim=1)
+    total = 0
+    for i in range(sm.shape[1]):
+        img = (torch.tanh(out[:, 2 * i:2 * i + 1]) + 1) / 2 * sm[:, i:i + 1]
+        seg = out[:, 2 * i + 1:2 * i + 2] * sm[:, i:i + 1]
+        total = total + torch.cat([img, seg], dim=1)
+    return total, torch.sigmoid(F.conv3d(sm, w_unc, b_unc))
+
+
 def unet_3d_3d(sd, images, img_channels, n_inputs, n_outputs, use_uncertainty=False,
                return_intermediate_feature=False):
     """FLAVR_arch.py:169-248.  NOTE: like the reference (:180-181) this subtracts
@@ -79,17 +93,8 @@ def unet_3d_3d(sd, images, img_channels, n_inputs, n_outputs, use_uncertainty=Fa
     if use_uncertainty:  # :203-227, :244-246
         dout = lrelu(F.conv2d(dout, sd["feature_fuse.conv.0.weight"], sd["feature_fuse.conv.0.bias"], 1, 1))
         out = F.conv2d(dout, sd["feature_fuse1.conv.0.weight"], sd["feature_fuse1.conv.0.bias"])
-        out = torch.stack(torch.split(out, out.shape[1] // n_outputs, dim=1), dim=2)
         ue = F.conv2d(dout, sd["uncertainty_early.conv.0.weight"], sd["uncertainty_early.conv.0.bias"])
-        ue = torch.stack(torch.split(ue, ue.shape[1] // n_outputs, dim=1), dim=2)
-        sm = torch.softmax(ue, dim=1)
-        total = 0
-        for i in range(sm.shape[1]):
-            img = (torch.tanh(out[:, 2 * i:2 * i + 1]) + 1) / 2 * sm[:, i:i + 1]
-            seg = out[:, 2 * i + 1:2 * i + 2] * sm[:, i:i + 1]
-            total = total + torch.cat([img, seg], dim=1)
-        unc = torch.sigmoid(F.conv3d(sm, sd["uncertainty_out.weight"], sd["uncertainty_out.bias"]))
-        return total, unc
+        return uasr_head(out, ue, sd["uncertainty_out.weight"], sd["uncertainty_out.bias"], n_outputs)
 
     out = lrelu(F.conv2d(dout, sd["feature_fuse.conv.0.weight"], sd["feature_fuse.conv.0.bias"], 1, 1))
     out = F.conv2d(F.pad(out, (3, 3, 3, 3), mode="reflect"), sd["outconv.1.weight"], sd["outconv.1.bias"])

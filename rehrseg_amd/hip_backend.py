@@ -547,6 +547,47 @@ def cosdist_bwd(x1, x2, stats, scale):
     return dx
 
 
+def _uasr_args(om, ue, wu, bu, D):
+    _chk_dev(om, ue, wu, bu)
+    for t in (om, ue, wu, bu):
+        if t.dtype != torch.float32:
+            raise L.RehrsegHipError("uasr_mix: float32 operands")
+    N, C2, one, H, W = om.shape
+    K = ue.shape[1] // D
+    if one != 1 or ue.shape != (N, K * D, 1, H, W) or C2 != 2 * K * D or wu.numel() != K or bu.numel() != 1:
+        raise ValueError(f"uasr_mix: om {tuple(om.shape)} / ue {tuple(ue.shape)} / D {D} / wu {tuple(wu.shape)}")
+    if K not in (4, 8, 16, 32):
+        raise NotImplementedError(f"uasr_mix: K = {K} candidates per slice (kernels: 4, 8, 16, 32)")
+    return N, K, H, W
+
+
+def uasr_mix_fwd(om, ue, wu, bu, D):
+    """om (N, D*2K, 1, H, W), ue (N, D*K, 1, H, W) NDHWC -> out (N, 2, D, H, W), unc (N, 1, D, H, W) (see the header)."""
+    N, K, H, W = _uasr_args(om, ue, wu, bu, D)
+    out = torch.empty((N, 2, D, H, W), dtype=torch.float32, device=om.device)
+    unc = torch.empty((N, 1, D, H, W), dtype=torch.float32, device=om.device)
+    L.check(L.load().rehr_uasr_mix_fwd_f32(_ptr(om), _ptr(ue), _ptr(wu), _ptr(bu), _ptr(out), _ptr(unc), N, K, D, H * W,
+                                           _stream()), "rehr_uasr_mix_fwd_f32")
+    return out, unc
+
+
+def uasr_mix_bwd(om, ue, wu, bu, gout, gunc, D):
+    """Gradients of uasr_mix_fwd: (dom, due, dwu (K,), dbu (1,)); gout / gunc dense NCDHW."""
+    N, K, H, W = _uasr_args(om, ue, wu, bu, D)
+    _chk_dev(gout, gunc)
+    if gout.shape != (N, 2, D, H, W) or gunc.shape != (N, 1, D, H, W) or not (gout.is_contiguous() and gunc.is_contiguous()):
+        raise ValueError("uasr_mix_bwd: gout (N,2,D,H,W) / gunc (N,1,D,H,W), contiguous")
+    dom = new_act(N, 2 * K * D, 1, H, W, like=om)
+    due = new_act(N, K * D, 1, H, W, like=ue)
+    lib = L.load()
+    blocks = lib.rehr_uasr_mix_blocks(N, D, H * W)
+    partial = torch.empty((blocks, K + 1), dtype=torch.float64, device=om.device)
+    L.check(lib.rehr_uasr_mix_bwd_f32(_ptr(om), _ptr(ue), _ptr(wu), _ptr(bu), _ptr(gout), _ptr(gunc), _ptr(dom), _ptr(due),
+                                      _ptr(partial), N, K, D, H * W, _stream()), "rehr_uasr_mix_bwd_f32")
+    tot = partial.sum(0).float()
+    return dom, due, tot[:K], tot[K:]
+
+
 def quad_maxpool_fwd(x):
     """x (N, C, D, H, W) NDHWC, H and W even -> (y (N*D, C, 2, 2) fp32 NHWC-dense, idx int32 same layout)."""
     _chk_dev(x)

@@ -140,6 +140,9 @@ PROTOTYPES = {
     "rehr_channel_sum_actgrad_f32": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),
     "rehr_cosdist_stats_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "rehr_cosdist_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, C.c_float, _vp]),
+    "rehr_uasr_mix_blocks": (_i32, [_i32, _i32, _i64]),
+    "rehr_uasr_mix_fwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    "rehr_uasr_mix_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "rehr_quad_maxpool_fwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_quad_maxpool_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_window_stem_assemble_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, C.c_float, _vp]),

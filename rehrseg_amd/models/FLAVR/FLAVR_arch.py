@@ -162,10 +162,14 @@ class UNet_3D_3D(nn.Module):
 
         if self.use_uncertainty:
             w1, b1 = self.feature_fuse1.as3d()
-            out = ops.fused_conv3d(fused, w1, b1, 1, 0)[:, :, 0]
-            out = torch.stack(torch.split(out, out.shape[1] // self.n_outputs, dim=1), dim=2)
+            out = ops.fused_conv3d(fused, w1, b1, 1, 0)
             we, be = self.uncertainty_early.as3d()
-            ue = ops.fused_conv3d(fused, we, be, 1, 0)[:, :, 0]
+            ue = ops.fused_conv3d(fused, we, be, 1, 0)
+            if not return_inetermediate_uncertainty and ops.uasr_mix_supported(out, ue, self.n_outputs):
+                # training / inference path: the candidate loop below as one pass (rehr_uasr_mix_*)
+                return ops.uasr_mix(out, ue, self.uncertainty_out.weight, self.uncertainty_out.bias, self.n_outputs)
+            out, ue = out[:, :, 0], ue[:, :, 0]
+            out = torch.stack(torch.split(out, out.shape[1] // self.n_outputs, dim=1), dim=2)
             ue = torch.stack(torch.split(ue, ue.shape[1] // self.n_outputs, dim=1), dim=2)
             sm = torch.softmax(ue, dim=1)
             out_multi, out = out, 0

@@ -639,3 +639,37 @@ def upsample_depth(x, scale):
     """Linear interpolation along depth only, align_corners=True (seg_model.py:204)."""
     Do = int(x.shape[2] * scale)
     return _UpsampleDepth.apply(x, Do)
+
+
+class _UasrMix(torch.autograd.Function):
+    """Softmax blend of the K candidate pairs + uncertainty of the UASR head -- see rehr_uasr_mix_fwd_f32."""
+
+    @staticmethod
+    def forward(ctx, om, ue, wu, bu, D):
+        om, ue = to_cl(om), to_cl(ue)
+        wu, bu = wu.reshape(-1).contiguous(), bu.reshape(-1).contiguous()
+        out, unc = get_backend().uasr_mix_fwd(om, ue, wu, bu, D)
+        ctx.save_for_backward(om, ue, wu, bu)
+        ctx.D = D
+        return out, unc
+
+    @staticmethod
+    def backward(ctx, gout, gunc):
+        om, ue, wu, bu = ctx.saved_tensors
+        gout, gunc = gout.contiguous(), gunc.contiguous()  # (an unused output arrives as zeros)
+        dom, due, dwu, dbu = get_backend().uasr_mix_bwd(om, ue, wu, bu, gout.to(om.dtype), gunc.to(om.dtype), ctx.D)
+        return dom, due, dwu, dbu, None
+
+
+def uasr_mix_supported(om, ue, n_outputs):
+    """The fused UASR head covers K = channels of `ue` per output slice in {4, 8, 16, 32}, two channels per candidate."""
+    return (om.dim() == 5 and om.shape[2] == 1 and ue.shape[1] % n_outputs == 0 and om.shape[1] == 2 * ue.shape[1]
+            and ue.shape[1] // n_outputs in (4, 8, 16, 32))
+
+
+def uasr_mix(om, ue, wu, bu, n_outputs):
+    """(out (N,2,n_outputs,H,W), unc (N,1,n_outputs,H,W)) of FLAVR's UASR head (reference FLAVR_arch.py:203-246) from the
+    two 1x1 responses on the fused slice, om (N, n_outputs*2K, 1, H, W) and ue (N, n_outputs*K, 1, H, W), and
+    uncertainty_out's weight (1,K,1,1,1) / bias.  Computed in fp32 (bf16 responses are widened first)."""
+    wide = lambda t: t.float() if t.dtype in (torch.bfloat16, torch.float16) else t  # noqa: E731
+    return _UasrMix.apply(wide(om), wide(ue), wide(wu).reshape(-1), wide(bu).reshape(-1), int(n_outputs))

@@ -287,6 +287,38 @@ def upmix_depth_bwd(dy, y, Di, KD, pd, act, slope):
     return dg.contiguous(memory_format=torch.channels_last_3d)
 
 
+def _uasr_parts(om, ue, wu, bu, D):
+    N, _, _, H, W = om.shape
+    K = ue.shape[1] // D
+    o = om[:, :, 0].reshape(N, D, K, 2, H, W)
+    s = torch.softmax(ue[:, :, 0].reshape(N, D, K, H, W), dim=2)
+    return o[:, :, :, 0], o[:, :, :, 1], s, wu.reshape(1, 1, K, 1, 1), K
+
+
+def uasr_mix_fwd(om, ue, wu, bu, D):
+    a, b, s, w, _ = _uasr_parts(om, ue, wu, bu, D)
+    out = torch.stack([(s * (torch.tanh(a) + 1) / 2).sum(2), (s * b).sum(2)], dim=1)
+    return out, torch.sigmoid((s * w).sum(2) + bu.reshape(1, 1, 1, 1)).unsqueeze(1)
+
+
+def uasr_mix_bwd(om, ue, wu, bu, gout, gunc, D):
+    a, b, s, w, K = _uasr_parts(om, ue, wu, bu, D)
+    N, _, _, H, W = om.shape
+    g0, g1 = gout[:, 0].unsqueeze(2), gout[:, 1].unsqueeze(2)   # (N, D, 1, H, W)
+    th = torch.tanh(a)
+    img = (th + 1) / 2
+    z = (s * w).sum(2, keepdim=True)
+    u = torch.sigmoid(z + bu.reshape(1, 1, 1, 1, 1))
+    gz = gunc[:, 0].unsqueeze(2) * u * (1 - u)
+    ds = g0 * img + g1 * b + gz * w
+    due = s * (ds - (s * ds).sum(2, keepdim=True))
+    dom = torch.stack([g0 * s * (1 - th * th) / 2, g1 * s], dim=3)  # (N, D, K, 2, H, W)
+    cl = torch.channels_last_3d
+    return (dom.reshape(N, D * K * 2, 1, H, W).contiguous(memory_format=cl),
+            due.reshape(N, D * K, 1, H, W).contiguous(memory_format=cl),
+            (gz * s).sum(dim=(0, 1, 3, 4)), gz.sum().reshape(1))
+
+
 def window_stem_assemble(g, mean, bias, B, nwin, act, slope):
     S, Cc, _, h, w = g[0].shape
     ns = nwin + 3

@@ -4,6 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle.flavr_oracle import uasr_head
 from rehrseg_amd import ops
 
 torch.manual_seed(0)
@@ -248,3 +249,24 @@ def test_split_k_low_resolution_stage(emu):
     g = torch.randn_like(ref)
     for a, e in zip(torch.autograd.grad(y, (x, w, ga, be), g), torch.autograd.grad(ref, (x, w, ga, be), g)):
         _cmp(a, e)
+
+
+@pytest.mark.parametrize("K,D,hw", [(16, 4, (5, 6)), (4, 3, (3, 3)), (32, 2, (4, 5))])
+def test_uasr_mix(emu, K, D, hw):
+    """The fused UASR head (contract of rehr_uasr_mix_*) against the candidate loop of the reference
+    (FLAVR_arch.py:203-246, oracle.flavr_oracle.uasr_head), values and all four gradients."""
+    N = 2
+    om = _rand(N, D * 2 * K, 1, *hw).requires_grad_()
+    ue = (2 * _rand(N, D * K, 1, *hw)).requires_grad_()
+    wu, bu = _rand(1, K, 1, 1, 1).requires_grad_(), _rand(1).requires_grad_()
+    assert ops.uasr_mix_supported(om, ue, D)
+    out, unc = ops.uasr_mix(om, ue, wu, bu, D)
+    ro, ru = uasr_head(om[:, :, 0], ue[:, :, 0], wu, bu, D)
+    _cmp(out, ro, 1e-6)
+    _cmp(unc, ru, 1e-6)
+    g0, g1 = torch.randn_like(ro), torch.randn_like(ru)
+    got = torch.autograd.grad([out, unc], [om, ue, wu, bu], [g0, g1])
+    ref = torch.autograd.grad([ro, ru], [om, ue, wu, bu], [g0, g1])
+    for a, e in zip(got, ref):
+        _cmp(a, e, 1e-6)
+    assert not ops.uasr_mix_supported(om, ue[:, :-1], D)

@@ -501,3 +501,27 @@ def test_winograd_wgrad_eight_wave_variant():
         hb.USE_WGRAD_8WAVE = saved
     assert torch.equal(out[True][0], out[False][0])
     assert torch.equal(out[True][1], out[False][1])
+
+
+@pytest.mark.parametrize("K,D,N,hw", [(16, 4, 2, (24, 40)), (4, 3, 1, (7, 9)), (8, 8, 3, (5, 5)), (32, 2, 2, (33, 17))])
+def test_uasr_mix(K, D, N, hw):
+    """rehr_uasr_mix_{fwd,bwd}_f32 against the reference's candidate loop in fp64 (oracle.flavr_oracle.uasr_head,
+    FLAVR_arch.py:203-246): blended image / segmentation, uncertainty, and the gradients of both 1x1 responses and of
+    uncertainty_out's weight and bias.  fp32 transcendental + summation-order differences only: 1e-5 of the scale."""
+    from oracle.flavr_oracle import uasr_head
+    om = _mk(N, D * 2 * K, 1, *hw, seed=81)
+    ue = 2 * _mk(N, D * K, 1, *hw, seed=82)
+    wu, bu = _mk(1, K, 1, 1, 1, seed=83), _mk(1, seed=84)
+    dev = _dev()
+    gin = [t.to(dev).requires_grad_() for t in (om, ue, wu, bu)]
+    rin = [t.double().requires_grad_() for t in (om, ue, wu, bu)]
+    assert ops.uasr_mix_supported(gin[0], gin[1], D)
+    out, unc = ops.uasr_mix(*gin, D)
+    ro, ru = uasr_head(rin[0][:, :, 0], rin[1][:, :, 0], rin[2], rin[3], D)
+    _close(out, ro, 1e-5)
+    _close(unc, ru, 1e-5)
+    g0, g1 = _mk(*ro.shape, seed=85), _mk(*ru.shape, seed=86)
+    got = torch.autograd.grad([out, unc], gin, [g0.to(dev), g1.to(dev)])
+    ref = torch.autograd.grad([ro, ru], rin, [g0.double(), g1.double()])
+    for a, e in zip(got, ref):
+        _close(a.reshape(e.shape), e, 1e-5)
