@@ -114,6 +114,13 @@ typedef struct {
 /* fp32 entry points: the 32-channel-tile Winograd kernel with one 1024-thread block per CU instead of two 512-thread ones */
 #define REHR_GG_W32_ONE_PER_CU 8
 
+/* fp32 entry points: planes that 16 x 16-output regions tile badly (12 x 12, 24 x 24, ...) on the flattened-tile
+ * kernel with the big-tile kernel's schedule (wino_flat8_conv.hip); _HALF / _FULL force 32 / 64 tiles per block
+ * (default: whichever fills 256 CUs better) */
+#define REHR_GG_FLAT8 32
+#define REHR_GG_FLAT8_HALF 64
+#define REHR_GG_FLAT8_FULL 128
+
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
 int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);

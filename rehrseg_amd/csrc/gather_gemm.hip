@@ -476,7 +476,8 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
     // launch (many depth taps, few tiles): one Winograd launch per part would run them one after the other on a
     // quarter of the chip, the generic kernel runs all parts in one grid
     if (descs[i].wino_ws != nullptr && !(count > 1 && descs[i].td.count > 3)) {
-      int wrc = wino_conv_try(descs[i], st);
+      int wrc = wino_flat8_conv_try(descs[i], st);
+      if (wrc == REHR_ENOSUP) wrc = wino_conv_try(descs[i], st);
       if (wrc == REHR_ENOSUP) wrc = wino22_conv_try(descs[i], st);
       if (wrc == REHR_ENOSUP) wrc = wino_flat_conv_try(descs[i], st);
       if (wrc == REHR_OK) continue;
@@ -497,7 +498,8 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
 
 extern "C" int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* dp) {
   if (dp == nullptr || validate(*dp) != REHR_OK) return 0;
-  int64_t b = wino_workspace_bytes(*dp);
+  int64_t b = wino_flat8_workspace_bytes(*dp);
+  if (b == 0) b = wino_workspace_bytes(*dp);
   if (b == 0) b = wino22_workspace_bytes(*dp);
   if (b == 0) b = wino_flat_workspace_bytes(*dp);
   return b;

@@ -13,3 +13,6 @@ int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
 int wino_weights_frag_launch(const rehr_gather_gemm_desc& d, int kchunks, hipStream_t stream);
 int64_t wino_flat_workspace_bytes(const rehr_gather_gemm_desc& d);
 int wino_flat_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
+// the same with the big-tile kernel's schedule and row-range staging (wino_flat8_conv.hip); tried first
+int64_t wino_flat8_workspace_bytes(const rehr_gather_gemm_desc& d);
+int wino_flat8_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);

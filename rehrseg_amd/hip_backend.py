@@ -157,6 +157,8 @@ USE_HALO_8WAVE = True   # mixed precision: the halo-brick kernel with eight wave
 USE_WGRAD_8WAVE = True   # Winograd weight gradient: the 64 x 64 block as 8 waves (two per SIMD)
 USE_WGRAD_TWO_PER_CU = False  # Winograd weight gradient: two 64 x 32 blocks per CU for the >= 64-channel layers
 USE_W32_TWO_PER_CU = False # fp32 32-channel-tile Winograd kernel: two 512-thread blocks per CU (False: one of 1024)
+USE_WINO_FLAT8 = True   # fp32 Winograd on planes that 16 x 16 regions tile badly: wino_flat8_conv_kernel
+WINO_FLAT8_TILES = 0    # 0: the library picks 32 or 64 tiles per block; 1 / 2 force 32 / 64 (tests, A/B)
 USE_WINO_8WAVE = True   # fp32 big-tile Winograd kernel: two waves per SIMD (wino_conv_big8_kernel)
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
 wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
@@ -198,13 +200,14 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     elif wp.dtype != torch.float32 or y.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
         raise L.RehrsegHipError("fp32 gather-GEMM: every operand must be float32")
     elif USE_WINOGRAD and tile[0] >= 0:
+        d.flags = ((L.GG_WINO_8WAVE if USE_WINO_8WAVE else 0) | (0 if USE_W32_TWO_PER_CU else L.GG_W32_ONE_PER_CU) |
+                   (L.GG_FLAT8 if USE_WINO_FLAT8 else 0) | {1: L.GG_FLAT8_HALF, 2: L.GG_FLAT8_FULL}.get(WINO_FLAT8_TILES, 0))
         nbytes = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
         if nbytes > 0:
             keep = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
             global wino_launches
             wino_launches += 1
             d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
-            d.flags = (L.GG_WINO_8WAVE if USE_WINO_8WAVE else 0) | (0 if USE_W32_TWO_PER_CU else L.GG_W32_ONE_PER_CU)
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0

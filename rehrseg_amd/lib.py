@@ -25,6 +25,9 @@ GG_NO_HALO = 2
 GG_WINO_8WAVE = 4
 GG_W32_ONE_PER_CU = 8
 GG_HALO_8WAVE = 16
+GG_FLAT8 = 32
+GG_FLAT8_HALF = 64
+GG_FLAT8_FULL = 128
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p

@@ -119,6 +119,64 @@ def test_winograd_conv(Cin, Cout, K, pad, dims):
     assert hip_backend.wino_launches - before == 2, "forward and input gradient should both take the Winograd path"
 
 
+FLAT8 = [  # tiles per block (0 = the library's pick, 1 = 32, 2 = 64), Cin, Cout, K, pad, dims
+    (1, 128, 128, (3, 3, 3), (1, 1, 1), (32, 4, 12, 12)),   # the reference's layer3 planes, two 32-tile blocks per CU
+    (2, 128, 128, (3, 3, 3), (1, 1, 1), (32, 4, 12, 12)),   # ... one 64-tile block per CU
+    (0, 32, 128, (3, 3, 3), (1, 1, 1), (7, 5, 24, 24)),    # layer2 planes (rows of 12 tiles), last block partly empty
+    (1, 48, 128, (3, 3, 3), (1, 1, 1), (40, 3, 13, 11)),   # odd extents, half last chunk
+    (2, 32, 192, (1, 3, 3), (0, 1, 1), (30, 2, 20, 28)),   # one depth tap, 3 channel tiles, 14-tile rows
+    (2, 32, 128, (3, 3, 3), (1, 1, 1), (128, 1, 12, 12)),   # depth 1: the outer depth taps are never reachable
+]
+
+
+@pytest.mark.parametrize("tiles,Cin,Cout,K,pad,dims", FLAT8)
+def test_winograd_flat8_conv(tiles, Cin, Cout, K, pad, dims, monkeypatch):
+    """wino_flat8_conv_kernel<1|2> (flattened tiles, row-range staging) forward + input gradient against fp64."""
+    from rehrseg_amd import hip_backend
+    monkeypatch.setattr(hip_backend, "WINO_FLAT8_TILES", tiles)
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=170)
+    w = _mk(Cout, Cin, *K, seed=171) / (Cin * K[0] * K[1] * K[2]) ** 0.5
+    b = _mk(Cout, seed=172)
+    before = hip_backend.wino_launches
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, pad, act=ops.ACT_LRELU, slope=0.1),
+         lambda x, w, b: F.leaky_relu(F.conv3d(x, w, b, 1, pad), 0.1), [x, w, b], [True, True, True])
+    # (the input gradient of the narrow layers has too few 64-channel units for this kernel and goes elsewhere)
+    assert hip_backend.wino_launches - before >= (2 if Cin >= 128 else 1)
+
+
+@pytest.mark.parametrize("tiles", [1, 2])
+def test_winograd_flat8_statistics_and_concat(tiles, monkeypatch):
+    """The per-(slice slot, channel) block sums of the flattened-tile kernel (SE mean, InstanceNorm mean / variance:
+    a block's tiles belong to up to three samples) and the two-source input of a decoder conv."""
+    from rehrseg_amd import hip_backend
+    monkeypatch.setattr(hip_backend, "WINO_FLAT8_TILES", tiles)
+    x = _mk(32, 64, 4, 12, 12, seed=180)
+    x2 = _mk(32, 32, 4, 12, 12, seed=181)
+    w = _mk(128, 96, 3, 3, 3, seed=182) / (96 * 27) ** 0.5
+    b = _mk(128, seed=183)
+    aw, ab = _mk(128, 128, 1, 1, 1, seed=184) / 11.0, _mk(128, seed=185)
+    _run(lambda x, x2, w, b, aw, ab: ops.fused_conv3d(x, w, b, 1, 1, x2=x2, se=(aw, ab), act=ops.ACT_LRELU, slope=0.2),
+         lambda x, x2, w, b, aw, ab: F.leaky_relu(_se(F.conv3d(torch.cat([x, x2], 1), w, b, 1, 1), aw, ab), 0.2),
+         [x, x2, w, b, aw, ab], [True] * 6)
+    ga, be = _mk(128, seed=186), _mk(128, seed=187)
+    _run(lambda x, x2, w, b, ga, be: ops.fused_conv3d(x, w, b, 1, 1, x2=x2, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
+         lambda x, x2, w, b, ga, be: F.leaky_relu(F.instance_norm(F.conv3d(torch.cat([x, x2], 1), w, b, 1, 1),
+                                                                  weight=ga, bias=be), 0.01),
+         [x, x2, w, b, ga, be], [True, True, True, False, True, True])
+
+
+def test_winograd_flat_conv_previous_kernel(monkeypatch):
+    """wino_flat_conv_kernel (16 waves, whole planes staged) stays selectable: REHR_GG_FLAT8 off."""
+    from rehrseg_amd import hip_backend
+    monkeypatch.setattr(hip_backend, "USE_WINO_FLAT8", False)
+    x = _mk(32, 64, 4, 12, 12, seed=190)
+    w = _mk(128, 64, 3, 3, 3, seed=191) / (64 * 27) ** 0.5
+    b = _mk(128, seed=192)
+    _run(lambda x, w, b: ops.fused_conv3d(x, w, b, 1, 1, act=ops.ACT_RELU),
+         lambda x, w, b: torch.relu(F.conv3d(x, w, b, 1, 1)), [x, w, b], [True, True, True])
+
+
 WINO_WGRAD = [  # weight gradients in the transform domain: >= 64 channels both sides, W >= 16
     (64, 64, (3, 3, 3), (1, 1, 1), (1, 4, 16, 32)),
     (128, 64, (3, 3, 3), (1, 1, 1), (2, 3, 8, 16)),
