@@ -121,6 +121,13 @@ typedef struct {
 #define REHR_GG_FLAT8_HALF 64
 #define REHR_GG_FLAT8_FULL 128
 
+/* fp32 entry points: the 32-channel-tile Winograd kernel (one block per CU) as 8 waves with the big-tile kernel's
+ * software pipeline instead of 16 waves of thread-level parallelism */
+#define REHR_GG_W32_PIPELINED 256
+/* ... forced as two 256-thread blocks per CU (16 x 16 outputs each) / one 512-thread block (default: by K length) */
+#define REHR_GG_W32P_TWO_PER_CU 512
+#define REHR_GG_W32P_ONE_PER_CU 1024
+
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
 int rehr_gather_gemm_f32(const rehr_gather_gemm_desc* d, void* stream);

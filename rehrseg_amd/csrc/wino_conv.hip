@@ -1212,6 +1212,292 @@ __global__ __launch_bounds__(256 * NFM, NFM == 2 ? 2 : 1) void wino_conv_w32_ker
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same 128 tiles x 32 channels block with the big-tile kernel's hand-built pipeline instead of 16 waves of
+// thread-level parallelism: 8 waves = (Winograd row r, tile-group pair g), two per SIMD; a wave owns TWO tile groups
+// (2 x 4 accumulator tiles) that share every weight fragment, so a k-group is 2 x 16 MFMAs per wave with the roles of
+// the big-tile kernel swapped: the A fragments alternate between two registers sets (V0 = group 2g, V1 = group 2g+1),
+// the weights ping-pong between k-groups.  Behind every 16 MFMAs: the other group's fragments are read and combined,
+// the next k-group's weights loaded, the next 16-channel item's patch fetched (step 0) and staged (step 2).
+// G = 2: 512 threads, 32 x 16 outputs, one block per CU.  G = 1: 256 threads, 16 x 16 outputs, two independent blocks
+// per CU -- with few input channels a block lives only a few K items, and one block's prologue / output transform then
+// runs behind the other block's MFMAs.
+template <int G>
+__global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel(const WinoParams p) {
+  constexpr int NTHR = 256 * G, VOX = W3<2 * G>::VOX, BUF = W3<2 * G>::BUF + 32;   // + a spare voxel slot
+  constexpr int W3P_NX = (VOX * 4 + NTHR - 1) / NTHR;                               // 16-byte pieces per thread
+  const rehr_gather_gemm_desc& d = p.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;  // [2][BUF]; reused as the exchange buffer at the end
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = wv & 3, g = wv >> 2;
+  const int half = lane >> 5, col = lane & 31;
+  const int n_img = blockIdx.z;
+  const int nt0 = blockIdx.y, n0 = blockIdx.y * 32;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int bw_ = b % p.nb_w; b /= p.nb_w;
+  const int bh_ = b % p.nb_h;
+  const int od = b / p.nb_h;
+  const int oh0 = bh_ * (16 * G), ow0 = bw_ * 16;
+
+  const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
+  const float s2 = (r == 1) ? 1.f : -1.f;
+  const float rsign = (r == 2) ? -1.f : 1.f;
+  // tile group 2g (+ W3P_GOFF floats: group 2g + 1 = tile rows +4 = patch rows +8)
+  const int th_ = g * 8 + (col >> 3), tw_ = col & 7;
+  const float* xa = Xs + (2 * th_ + i1) * W3_RP + tw_ * W3_LD + 4 * half;
+  const float* xb = Xs + (2 * th_ + i2) * W3_RP + tw_ * W3_LD + 4 * half;
+  constexpr int GOFF = 8 * W3_RP;
+
+  int pvx[W3P_NX];
+  uint32_t pok = 0;
+#pragma unroll
+  for (int i = 0; i < W3P_NX; ++i) {
+    const int piece = tid + NTHR * i;
+    const int v = piece >> 2;
+    const int ph = v / PW2, slot = v - ph * PW2;
+    const int pw_ = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
+    const int ih = oh0 + p.dh0 + ph, iw = ow0 + p.dw0 + pw_;
+    const bool ok = (piece < VOX * 4) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+    pvx[i] = ok ? ih * d.Wi + iw : 0;
+    pok |= (ok ? 1u : 0u) << i;
+  }
+  const int pq = tid & 3;
+  const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
+  const int nhalf = (d.Cin + 15) / 16;
+  int jd_lo = d.td.count, jd_hi = -1;
+  for (int j = 0; j < d.td.count; ++j) {
+    const int id = od + d.bd + d.td.off0 + d.td.offs * j;
+    if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
+  }
+  const int items = nhalf * max(0, jd_hi - jd_lo + 1);
+  struct Item { int h16, jd; };
+  auto advance = [&](Item& t) {
+    if (++t.jd > jd_hi) { t.jd = jd_lo; ++t.h16; }
+  };
+  f32x4 rx[W3P_NX];
+  auto fetch = [&](const Item& t) {
+    const bool live = (t.h16 < nhalf) & (items > 0);
+    const int jd = t.jd;
+    const int cc = (live ? t.h16 : 0) * 16;
+    const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
+    const bool first = cc < d.c1;
+    const float* src = first ? d.x1 : d.x2;
+    const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
+    const int coff = first ? cc : cc - d.c1;
+    const uint32_t nrec = img_elems * ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(src) + (int64_t)n_img * img_elems * ld, 0, nrec, 0x00020000);
+    const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
+    const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
+#pragma unroll
+    for (int i = 0; i < W3P_NX; ++i) {
+      const bool ok = dok & ((pok >> i) & 1u);
+      const uint32_t off = base + (uint32_t)pvx[i] * ld * 4u;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < W3P_NX; ++i) {
+      // (pieces past the patch -- zeros -- land in one spare slot behind the buffer: no divergent branch in the loop)
+      const int v = min((tid + NTHR * i) >> 2, VOX), row = (v * 3641) >> 16;  // v / 18 for v < 1024
+      *reinterpret_cast<f32x4*>(Xs + buf + v * W3_LD + row * 8 + pq * 4) = rx[i];
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rsu =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
+  const int NT = d.Npad / 32;
+  const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
+  const uint32_t ulane = (uint32_t)lane * 16u, ubase = (uint32_t)(r * 4) * xi_stride + (uint32_t)nt0 * nt_stride;
+  auto load_u = [&](const Item& t, const int kkl, f32x4 (&ub)[4]) {
+    const int h16 = t.h16 < nhalf ? t.h16 : 0;  // (one item past the end is requested, never used)
+    const uint32_t base = ubase + (uint32_t)(t.jd * 16) * xi_stride +
+                          (uint32_t)((h16 >> 1) * 4 + (h16 & 1) * 2 + kkl) * 1024u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, base + c * xi_stride, 0));
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[m][c][q] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  auto issue_reads = [&](int buf, const int m, const int kkl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = buf + m * GOFF + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8;
+      ra[j] = *reinterpret_cast<const f32x4*>(xa + o);
+      rb[j] = *reinterpret_cast<const f32x4*>(xb + o);
+    }
+  };
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  struct VFrag { f32x2 p[4][2]; };
+  const f32x2 s2v = {s2, s2};
+  auto combine = [&](VFrag& v) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x2 R[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 a = h ? ra[j].hi : ra[j].lo, bq = h ? rb[j].hi : rb[j].lo;
+        R[j] = __builtin_elementwise_fma(bq, s2v, a);
+      }
+      v.p[0][h] = R[0] - R[2];
+      v.p[1][h] = R[1] + R[2];
+      v.p[2][h] = R[1] - R[2];  // negated column, undone at the output
+      v.p[3][h] = R[1] - R[3];
+    }
+  };
+  auto mfmas = [&](const int m, const VFrag& v, const f32x4 (&ub)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.p[c][e >> 1][e & 1], ub[c][e], acc[m][c], 0, 0, 0);
+  };
+
+  VFrag V0, V1;
+  f32x4 u0[4], u1[4];
+  Item ci = {0, min(jd_lo, d.td.count - 1)}, ni = ci;
+  fetch(ci);
+  load_u(ci, 0, u0);
+  load_u(ci, 1, u1);
+  stage(0);
+  __syncthreads();
+  issue_reads(0, 0, 0);
+  combine(V0);
+
+#define W3P_FENCE() __builtin_amdgcn_sched_barrier(0)
+  for (int it = 0; it < items; ++it) {
+    const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
+    advance(ni);
+    // step 0: (group 0, k-group 0)
+    W3P_FENCE();
+    issue_reads(cur, 1, 0);
+    fetch(ni);
+    mfmas(0, V0, u0);
+    combine(V1);
+    // step 1: (group 1, k-group 0); u0 is released behind it
+    W3P_FENCE();
+    issue_reads(cur, 0, 1);
+    mfmas(1, V1, u0);
+    combine(V0);
+    W3P_FENCE();
+    load_u(ni, 0, u0);
+    // step 2: (group 0, k-group 1)
+    W3P_FENCE();
+    issue_reads(cur, 1, 1);
+    stage(nxt);
+    mfmas(0, V0, u1);
+    combine(V1);
+    // the next item's patch is complete and nobody reads the current one any more (step 3's fragments are in V1):
+    // the barrier goes HERE, so that the next item's first fragments are read and combined behind step 3's MFMAs
+    W3P_FENCE();
+    __syncthreads();
+    // step 3: (group 1, k-group 1); u1 is released behind it
+    W3P_FENCE();
+    issue_reads(nxt, 0, 0);
+    mfmas(1, V1, u1);
+    combine(V0);
+    W3P_FENCE();
+    load_u(ni, 1, u1);
+    ci = ni;
+  }
+#undef W3P_FENCE
+  __syncthreads();
+
+  // ---- output transform: columns in registers, rows across the 4 row-waves of a tile group through LDS
+  float* ex = smem;  // [fm][r][c'][q][lane], fm = 2 g + m
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const f32x16 T0 = (acc[m][0] + acc[m][1] - acc[m][2]) * rsign;
+    const f32x16 T1 = (acc[m][1] + acc[m][2] - acc[m][3]) * rsign;
+    float* e0 = ex + (((2 * g + m) * 4 + r) * 2) * 16 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      e0[q * 64] = T0[q];
+      e0[(16 + q) * 64] = T1[q];
+    }
+  }
+  __syncthreads();
+  const int ro = r >> 1, co = r & 1;
+  const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
+  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
+  float* ybase = d.y + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
+                 n0 + col;
+  const int64_t rowstep = 2 * (int64_t)d.Wy * d.ldy, colstep = 2 * (int64_t)d.ldy;
+  const bool interior = (oh0 + 16 * G <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 32 <= d.Cout);
+  const int col_n = n0 + col;
+  const bool colok = col_n < d.Cout;
+  const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
+  float s1_ = 0.f, s2_ = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int fm = 2 * g + m;
+    const float* e0 = ex + (fm * 4 * 2 + co) * 16 * 64 + lane;
+    float t[4][16];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + k3 * t[3][q] + bv;
+      v[q] = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
+    }
+    float* yb = ybase + (fm * 4) * rowstep;
+    if (interior) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
+        s1_ += v[q];
+        s2_ += v[q] * v[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
+        const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
+        if (ok) yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
+        s1_ += ok ? v[q] : 0.f;
+        s2_ += ok ? v[q] * v[q] : 0.f;
+      }
+    }
+  }
+  if (d.stats_mode != 0) {  // block-level sums first: one atomic per column and block
+    s1_ += __shfl_xor(s1_, 32, 64);
+    s2_ += __shfl_xor(s2_, 32, 64);
+    __syncthreads();  // everybody is done reading ex
+    float* red = smem;  // [wave][2][32]
+    if (half == 0) {
+      red[(wv * 2 + 0) * 32 + col] = s1_;
+      red[(wv * 2 + 1) * 32 + col] = s2_;
+    }
+    __syncthreads();
+    if (wv == 0 && half == 0 && colok) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4 * G; ++w) {
+        a1 += red[(w * 2 + 0) * 32 + col];
+        a2 += red[(w * 2 + 1) * 32 + col];
+      }
+      double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
+      atomicAdd(st, (double)a1);
+      if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
+    }
+  }
+}
+
 bool three_taps(const rehr_axis_taps& t, int b) {
   if (t.count != 3) return false;
   const int o0 = b + t.off0, o1 = b + t.off0 + t.offs, o2 = b + t.off0 + 2 * t.offs;
@@ -1230,6 +1516,23 @@ int w32_groups(const rehr_gather_gemm_desc& d) {
     if (d.Lh >= 32 && nb_h * 32 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13) return 4;
   }
   return 2;
+}
+
+template <int G>
+int launch_w32p(const WinoParams& p, const rehr_gather_gemm_desc& d, hipStream_t stream) {
+  const size_t smem_x = (size_t)2 * (W3<2 * G>::BUF + 32) * sizeof(float);
+  const size_t smem_e = (size_t)2 * G * 4 * 2 * 16 * 64 * sizeof(float);
+  const size_t smem = smem_x > smem_e ? smem_x : smem_e;
+  static bool attr_set32p = false;
+  if (!attr_set32p) {
+    if (hipFuncSetAttribute((const void*)wino_conv_w32p_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return REHR_EHIP;
+    attr_set32p = true;
+  }
+  dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 32, d.N);
+  hipLaunchKernelGGL(wino_conv_w32p_kernel<G>, grid, dim3(256 * G), smem, stream, p);
+  return REHR_OK;
 }
 
 template <int NFM>
@@ -1360,7 +1663,18 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     const int nfm = w32_groups(d);
     p.nb_h = (d.Lh + 8 * nfm - 1) / (8 * nfm);
     p.nb_w = (d.Lw + 15) / 16;
-    const int rc = nfm == 4 ? launch_w32<4>(p, d, stream) : launch_w32<2>(p, d, stream);
+    int rc;
+    if (d.flags & REHR_GG_W32_PIPELINED) {
+      // few K items per block (<= 32 input channels): two half-size blocks per CU hide each other's turnover (2 %)
+      const bool two = (d.flags & REHR_GG_W32P_TWO_PER_CU) ? true : (d.flags & REHR_GG_W32P_ONE_PER_CU) ? false
+                                                                   : d.Cin * d.td.count <= 96;
+      const int g = (nfm == 4 && !two) ? 2 : 1;
+      p.nb_h = (d.Lh + 16 * g - 1) / (16 * g);
+      rc = g == 2 ? launch_w32p<2>(p, d, stream) : launch_w32p<1>(p, d, stream);
+      if (rc != REHR_OK) return rc;
+    } else {
+      rc = nfm == 4 ? launch_w32<4>(p, d, stream) : launch_w32<2>(p, d, stream);
+    }
     if (rc != REHR_OK) return rc;
     REHR_LAUNCH_CHECK();
     return REHR_OK;

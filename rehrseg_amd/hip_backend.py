@@ -32,13 +32,16 @@ def profile_start():
     _prof = []
 
 
-def profile_stop():
-    """-> {family: {"flops", "seconds", "launches"}} summed over the recorded launches."""
+def profile_stop(layers=False):
+    """-> {family: {"flops", "seconds", "launches"}} summed over the recorded launches; layers=True: the launches one by
+    one as (family, shape tag, flops, seconds) instead (tools/layer_times.py)."""
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
+    if layers:
+        return [(fam, tag, flops, e0.elapsed_time(e1) * 1e-3) for fam, flops, e0, e1, tag in rec or []]
     out = {}
-    for fam, flops, e0, e1 in rec or []:
+    for fam, flops, e0, e1, _ in rec or []:
         d = out.setdefault(fam, {"flops": 0.0, "seconds": 0.0, "launches": 0})
         d["flops"] += flops
         d["seconds"] += e0.elapsed_time(e1) * 1e-3
@@ -68,8 +71,8 @@ def _algo_flops(N, lattice, s, b, taps, dims, c_a, c_b):
 
 
 class _timed:
-    def __init__(self, fam, flops):
-        self.fam, self.flops = fam, flops
+    def __init__(self, fam, flops, tag=None):
+        self.fam, self.flops, self.tag = fam, flops, tag
 
     def __enter__(self):
         if _prof is not None:
@@ -81,7 +84,7 @@ class _timed:
     def __exit__(self, *exc):
         if _prof is not None:
             self.e1.record()
-            _prof.append((self.fam, self.flops, self.e0, self.e1))
+            _prof.append((self.fam, self.flops, self.e0, self.e1, self.tag() if callable(self.tag) else self.tag))
         return False
 
 
@@ -157,6 +160,8 @@ USE_HALO_8WAVE = True   # mixed precision: the halo-brick kernel with eight wave
 USE_WGRAD_8WAVE = True   # Winograd weight gradient: the 64 x 64 block as 8 waves (two per SIMD)
 USE_WGRAD_TWO_PER_CU = False  # Winograd weight gradient: two 64 x 32 blocks per CU for the >= 64-channel layers
 USE_W32_TWO_PER_CU = False # fp32 32-channel-tile Winograd kernel: two 512-thread blocks per CU (False: one of 1024)
+USE_W32_PIPELINED = True   # fp32 32-channel-tile Winograd kernel: 8 waves, software-pipelined (wino_conv_w32p_kernel)
+W32P_BLOCKS = 0   # 0: the library picks; 1 / 2 force two 256-thread blocks per CU / one 512-thread block (tests, A/B)
 USE_WINO_FLAT8 = True   # fp32 Winograd on planes that 16 x 16 regions tile badly: wino_flat8_conv_kernel
 WINO_FLAT8_TILES = 0    # 0: the library picks 32 or 64 tiles per block; 1 / 2 force 32 / 64 (tests, A/B)
 USE_WINO_8WAVE = True   # fp32 big-tile Winograd kernel: two waves per SIMD (wino_conv_big8_kernel)
@@ -201,7 +206,7 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
         raise L.RehrsegHipError("fp32 gather-GEMM: every operand must be float32")
     elif USE_WINOGRAD and tile[0] >= 0:
         d.flags = ((L.GG_WINO_8WAVE if USE_WINO_8WAVE else 0) | (0 if USE_W32_TWO_PER_CU else L.GG_W32_ONE_PER_CU) |
-                   (L.GG_FLAT8 if USE_WINO_FLAT8 else 0) | {1: L.GG_FLAT8_HALF, 2: L.GG_FLAT8_FULL}.get(WINO_FLAT8_TILES, 0))
+                   (L.GG_FLAT8 if USE_WINO_FLAT8 else 0) | (L.GG_W32_PIPELINED if USE_W32_PIPELINED else 0) | {1: L.GG_W32P_TWO_PER_CU, 2: L.GG_W32P_ONE_PER_CU}.get(W32P_BLOCKS, 0) | {1: L.GG_FLAT8_HALF, 2: L.GG_FLAT8_FULL}.get(WINO_FLAT8_TILES, 0))
         nbytes = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
         if nbytes > 0:
             keep = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
@@ -211,6 +216,11 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
+
+
+def _gg_tag(d):
+    return (f"N{d.N} {d.Cin}->{d.Cout} lattice {d.Ld}x{d.Lh}x{d.Lw} stride {d.sd}{d.sh}{d.sw} "
+            f"taps {d.td.count}x{d.th.count}x{d.tw.count}" + (" +x2" if d.x2 else ""))
 
 
 def _gg_family(d):
@@ -227,7 +237,7 @@ def gather_gemm(*args):
         with _timed("gather_gemm_bf16", flops):
             L.check(L.load().rehr_gather_gemm_bf16(C.byref(d), _stream()), "rehr_gather_gemm_bf16")
         return
-    with _timed(_gg_family(d), flops):
+    with _timed(_gg_family(d), flops, lambda: _gg_tag(d)):
         L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
 
 
@@ -244,7 +254,8 @@ def gather_gemm_multi(calls):
         with _timed("gather_gemm_bf16", flops):
             L.check(L.load().rehr_gather_gemm_multi_bf16(arr, len(calls), _stream()), "rehr_gather_gemm_multi_bf16")
         return
-    with _timed(_gg_family(arr[0]) if all(arr[i].wino_ws for i in range(len(calls))) else "gather_gemm", flops):
+    with _timed(_gg_family(arr[0]) if all(arr[i].wino_ws for i in range(len(calls))) else "gather_gemm", flops,
+                lambda: f"{len(calls)} parts of " + _gg_tag(arr[0])):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 
 
@@ -308,7 +319,8 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     wino_wgrad_launches += wino
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
     d.workspace, d.workspace_bytes = _ptr(ws), nbytes
-    with _timed(("wino_wgrad" if d.th.count == 3 else "wino22_wgrad") if wino else "wgrad", flops):
+    with _timed(("wino_wgrad" if d.th.count == 3 else "wino22_wgrad") if wino else "wgrad", flops,
+                lambda: f"N{N} {Ca}x{Cg} lattice {tuple(lattice)} stride {tuple(s)} taps {taps[0][0]}x{taps[1][0]}x{taps[2][0]}"):
         L.check(lib.rehr_wgrad_f32(C.byref(d), _stream()), "rehr_wgrad_f32")
 
 

@@ -28,6 +28,9 @@ GG_HALO_8WAVE = 16
 GG_FLAT8 = 32
 GG_FLAT8_HALF = 64
 GG_FLAT8_FULL = 128
+GG_W32_PIPELINED = 256
+GG_W32P_TWO_PER_CU = 512
+GG_W32P_ONE_PER_CU = 1024
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p

@@ -522,6 +522,32 @@ def test_winograd_w32_two_per_cu_variant():
     assert torch.equal(out[True][0], out[False][0])
 
 
+@pytest.mark.parametrize("blocks", [1, 2])
+@pytest.mark.parametrize("dims,Cin,Cout", [((2, 4, 64, 48), 32, 32), ((1, 3, 60, 30), 48, 96), ((1, 2, 33, 50), 48, 32)])
+def test_winograd_w32_pipelined_variant(dims, Cin, Cout, blocks, monkeypatch):
+    """wino_conv_w32p_kernel (8 waves, software pipeline) against wino_conv_w32_kernel<4> (16 waves): the same products
+    in the same order per accumulator -> the same bits, statistics included; ragged regions and a half last chunk."""
+    from rehrseg_amd import hip_backend as hb
+    monkeypatch.setattr(hb, "W32P_BLOCKS", blocks)   # 1: two 256-thread blocks per CU, 2: one 512-thread block
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=164).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = (_mk(Cout, Cin, 3, 3, 3, seed=165) / (27 * Cin) ** 0.5).to(_dev())
+    b = _mk(Cout, seed=166).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    saved = hb.USE_W32_PIPELINED
+    try:
+        out = {}
+        for flag in (False, True):
+            hb.USE_W32_PIPELINED = flag
+            out[flag] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.01, 2)
+    finally:
+        hb.USE_W32_PIPELINED = saved
+    assert torch.equal(out[True][0], out[False][0])
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-6, atol=1e-6)
+    ref = F.leaky_relu(F.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), 1, 1), 0.01)
+    _close(out[True][0], ref)
+
+
 def test_winograd_wgrad_two_per_cu_variant():
     """REHR_WGRAD_TWO_PER_CU (two 64 x 32 blocks per CU) against the 64 x 64 blocking: same products, another split."""
     from rehrseg_amd import hip_backend as hb

@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rehrseg_amd import ops, hip_backend
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:   # tiles per block of the flattened-tile kernel: 0 = the library's pick, 1 = 32, 2 = 64
+    hip_backend.WINO_FLAT8_TILES = int(sys.argv[1])
+    print("WINO_FLAT8_TILES =", hip_backend.WINO_FLAT8_TILES)
 def t(f, n=5):
     f(); f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
