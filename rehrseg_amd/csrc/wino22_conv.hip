@@ -320,10 +320,16 @@ bool plan22(const rehr_gather_gemm_desc& d, W22Params& p) {
   if (ah.nph != aw.nph) return false;                    // (2-tap, 2-tap) phases or (4-tap, 4-tap) stride-2 gathers
   if (ah.nph == 2 && (d.osh != 1 || d.osw != 1 || d.obh || d.obw)) return false;
   if (d.td.count < 1 || d.td.count > 3) return false;
-  if (d.Npad % 64 || d.Lh < 16 || d.Lw < 16) return false;
+  if (d.Npad % 64 || d.Lh < 12 || d.Lw < 12) return false;
   p.nb_h = (d.Lh + 15) / 16;
   p.nb_w = (d.Lw + 15) / 16;
-  if ((int64_t)p.nb_h * 16 * p.nb_w * 16 * 10 > (int64_t)d.Lh * d.Lw * 13) return false;
+  // padding to whole 16 x 16 regions: up to 1.3x always; up to 1.78x (12 x 12, 24 x 24 planes: the reference's own crops)
+  // when the grid still fills the chip -- the padded transform-domain kernel then equals the direct kernel's MFMA count
+  // at a better utilisation
+  const int64_t padded = (int64_t)p.nb_h * 16 * p.nb_w * 16, exact = (int64_t)d.Lh * d.Lw;
+  if (padded * 10 > exact * 13) {
+    if (padded * 100 > exact * 178 || (int64_t)p.nb_h * p.nb_w * d.Ld * d.N * (d.Npad / 64) < 256) return false;
+  }
   p.d = d;
   p.kchunks = (d.Cin + 31) / 32;
   p.nphase = ah.nph * aw.nph;
