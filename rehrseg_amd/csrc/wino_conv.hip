@@ -861,18 +861,20 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
     BIG8_KGROUP(0, VA, VB, ci, 1, issue_reads(cur, 1), fetch(ni, 0), (void)0)
     BIG8_KGROUP(1, VB, VA, ci, 2, issue_reads(cur, 2), (void)0, stage(nxt, 0))
     BIG8_KGROUP(2, VA, VB, ci, 3, issue_reads(cur, 3), fetch(ni, NXH), (void)0)
-    // last k-group of the item: its A fragments are in VB; the next item's come after the barrier
+    // last k-group of the item: its A fragments are in VB and nobody reads the current patch any more, so the barrier
+    // sits between its two half steps and the next item's first fragments are read and combined behind 16 MFMAs
     __builtin_amdgcn_sched_barrier(0);
+    stage(nxt, NXH);
     mfmas(0, VB, u0);
     __builtin_amdgcn_sched_barrier(0);
     load_u(ni, 0, 0, u0);
-    stage(nxt, NXH);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_reads(nxt, 0);
     mfmas(1, VB, u1);
+    combine(VA);
     __builtin_amdgcn_sched_barrier(0);
     load_u(ni, 0, 1, u1);
-    __syncthreads();
-    issue_reads(nxt, 0);
-    combine(VA);
     ci = ni;
   }
 #undef BIG8_KGROUP

@@ -249,17 +249,20 @@ __global__ __launch_bounds__(256 * NFM, NFM == 1 ? 2 : 1) void wino_flat8_conv_k
     F8_KGROUP(VA, VB, ci, 1, issue_reads(cur, 1), fetch(ni, 0), (void)0)
     F8_KGROUP(VB, VA, ci, 2, issue_reads(cur, 2), (void)0, stage(nxt, 0))
     F8_KGROUP(VA, VB, ci, 3, issue_reads(cur, 3), fetch(ni, F8_NXH), (void)0)
+    // last k-group: nobody reads the current rows any more (its fragments are in VB), so the barrier sits between its
+    // two half steps and the next item's first fragments are read and combined behind 16 MFMAs
     F8_FENCE();
+    stage(nxt, F8_NXH);
     mfmas(0, VB, u0);
     F8_FENCE();
     load_u(ni, 0, 0, u0);
-    stage(nxt, F8_NXH);
+    __syncthreads();
+    F8_FENCE();
+    issue_reads(nxt, 0);
     mfmas(1, VB, u1);
+    combine(VA);
     F8_FENCE();
     load_u(ni, 0, 1, u1);
-    __syncthreads();
-    issue_reads(nxt, 0);
-    combine(VA);
     ci = ni;
   }
 #undef F8_KGROUP

@@ -11,7 +11,8 @@ import re
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librehrseg_hip.so")
+# REHRSEG_HIP_LIB: another build of the same ABI (kernel A/B runs, tools/ab_lib.py); default = the in-tree library
+LIB_PATH = os.environ.get("REHRSEG_HIP_LIB") or os.path.join(_HERE, "librehrseg_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rehrseg_hip.h")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
