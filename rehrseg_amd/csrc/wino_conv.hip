@@ -1441,7 +1441,9 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel
   const int col_n = n0 + col;
   const bool colok = col_n < d.Cout;
   const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
-  float s1_ = 0.f, s2_ = 0.f;
+  // statistics in double from the first addition on: a thread sums 32 values here, and InstanceNorm's variance
+  // (E[y^2] - mean^2) amplifies every systematic rounding of the two sums
+  double s1_ = 0.0, s2_ = 0.0;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int fm = 2 * g + m;
@@ -1462,8 +1464,8 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
-        s1_ += v[q];
-        s2_ += v[q] * v[q];
+        s1_ += (double)v[q];
+        s2_ += (double)v[q] * (double)v[q];
       }
     } else {
 #pragma unroll
@@ -1471,8 +1473,8 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel
         const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
         const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
         if (ok) yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
-        s1_ += ok ? v[q] : 0.f;
-        s2_ += ok ? v[q] * v[q] : 0.f;
+        s1_ += ok ? (double)v[q] : 0.0;
+        s2_ += ok ? (double)v[q] * (double)v[q] : 0.0;
       }
     }
   }
@@ -1480,22 +1482,22 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel
     s1_ += __shfl_xor(s1_, 32, 64);
     s2_ += __shfl_xor(s2_, 32, 64);
     __syncthreads();  // everybody is done reading ex
-    float* red = smem;  // [wave][2][32]
+    double* red = reinterpret_cast<double*>(smem);  // [wave][2][32]
     if (half == 0) {
       red[(wv * 2 + 0) * 32 + col] = s1_;
       red[(wv * 2 + 1) * 32 + col] = s2_;
     }
     __syncthreads();
     if (wv == 0 && half == 0 && colok) {
-      float a1 = 0.f, a2 = 0.f;
+      double a1 = 0.0, a2 = 0.0;
 #pragma unroll
       for (int w = 0; w < 4 * G; ++w) {
         a1 += red[(w * 2 + 0) * 32 + col];
         a2 += red[(w * 2 + 1) * 32 + col];
       }
       double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
-      atomicAdd(st, (double)a1);
-      if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
+      atomicAdd(st, a1);
+      if (d.stats_mode == 2) atomicAdd(st + 1, a2);
     }
   }
 }
