@@ -313,6 +313,355 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Flattened-tile variant for planes that whole 16 x 16 regions pad badly (12 x 12, 24 x 24: the transposed
+// convolutions of the reference's own 96 x 96 crops): the 2 x 2 tiles of all slices are numbered consecutively (slice =
+// depth-major, od * N + n), a block takes 64 consecutive tiles x 64 channels and stages the contiguous range of rows they
+// read in the index space slice * (2 nth + 1) + lattice row -- the organisation of wino_flat8_conv.hip; compute loop,
+// weight panel and summation order are this file's.
+constexpr int F22_NX = 5;        // 16-byte pieces per thread
+constexpr int F22_MAXSLOT = 8;   // slices a block may touch
+
+struct F22Params {
+  rehr_gather_gemm_desc d;
+  int kchunks, nphase;
+  Phase phase[MAXPH];
+  const float* up;
+  uint32_t up_bytes;
+  int nth, ntw, tps, ntiles, PH, PWs, nev, RP, rowpad, rows, rowmagic, tab_off;
+};
+
+__global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p) {
+  constexpr int TB = 64;
+  const rehr_gather_gemm_desc& d = p.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+  const int FBUF = p.rows * p.RP + LD + 4;   // + a spare voxel slot
+  const int vtrash = p.rows * p.PWs;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = wv % 3, fm = (wv / 3) & 1, fn = wv / 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int nt0 = blockIdx.y * 2 + fn, n0 = blockIdx.y * 64;
+  const int T0 = blockIdx.x * TB;
+  const int Tl = min(T0 + TB, p.ntiles) - 1;
+  const int s0 = T0 / p.tps, sl_ = Tl / p.tps;
+  const int G0 = s0 * p.PH + 2 * ((T0 - s0 * p.tps) / p.ntw);
+  const int rowsB = sl_ * p.PH + 2 * ((Tl - sl_ * p.tps) / p.ntw) + 3 - G0;   // <= p.rows (planner)
+
+  int* tab = reinterpret_cast<int*>(smem + p.tab_off);
+  if (tid < TB) {
+    const int T = T0 + tid;
+    const int s = T / p.tps, tt = T - s * p.tps;
+    const int th = tt / p.ntw, tw = tt - th * p.ntw;
+    const int od = s / d.N, n = s - od * d.N;
+    tab[tid] = T < p.ntiles ? ((n * d.Dy + od * d.osd + d.obd) * d.Hy + 2 * th * d.osh + d.obh) * d.Wy + 2 * tw * d.osw + d.obw
+                            : -1;
+    tab[TB + tid] = min(s - s0, F22_MAXSLOT - 1);
+    tab[2 * TB + tid] = (th << 16) | tw;
+  }
+
+  const int ia = r;
+  const float *xa, *xb;
+  {
+    const int T = min(T0 + fm * 32 + col, p.ntiles - 1);
+    const int s = T / p.tps, tt = T - s * p.tps;
+    const int th = tt / p.ntw, tw = tt - th * p.ntw;
+    const int grow = s * p.PH + 2 * th - G0;
+    xa = Xs + (grow + ia) * p.RP + tw * LD + 4 * half;
+    xb = Xs + (grow + 1) * p.RP + tw * LD + 4 * half;
+  }
+  const int off_odd = p.nev * LD;   // patch column 2*tw + j -> slot (j & 1) * nev + tw + (j >> 1)
+
+  // staging pieces: (row, slot, channel quad) -> sample/depth base, lattice (row, column), live bit
+  int pnd[F22_NX], prc[F22_NX];
+  uint32_t pok = 0;
+  const int v0 = tid >> 3, pq = tid & 7;
+#pragma unroll
+  for (int i = 0; i < F22_NX; ++i) {
+    const int v = v0 + (NT_ / 8) * i;
+    const int row = (v * p.rowmagic) >> 16, slot = v - row * p.PWs;
+    const int Gr = G0 + row;
+    const int s = Gr / p.PH, lr = Gr - s * p.PH;
+    const int od = s / d.N, n = s - od * d.N;
+    const int lc = slot < p.nev ? 2 * slot : 2 * (slot - p.nev) + 1;
+    const bool ok = (row < rowsB) & (od < d.Ld);
+    pnd[i] = ok ? n * d.Di + od : 0;
+    prc[i] = (od << 24) | (lr << 12) | lc;     // od < 128, lr / lc < 4096 (planner)
+    pok |= (ok ? 1u : 0u) << i;
+  }
+  int jd_lo = d.td.count, jd_hi = -1;
+  {
+    const int od_a = s0 / d.N, od_b = min(sl_ / d.N, d.Ld - 1);
+    for (int j = 0; j < d.td.count; ++j) {
+      const int dd = d.bd + d.td.off0 + d.td.offs * j;
+      if (od_b + dd >= 0 && od_a + dd < d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
+    }
+  }
+  const int items = p.nphase * p.kchunks * max(0, jd_hi - jd_lo + 1);
+  f32x4 rx[F22_NX];
+  struct Item { int ph, chunk, jd; };
+  auto advance = [&](Item& t) {
+    if (++t.jd > jd_hi) {
+      t.jd = jd_lo;
+      if (++t.chunk == p.kchunks) { t.chunk = 0; ++t.ph; }
+    }
+  };
+  const uint32_t tot1 = (uint32_t)d.N * d.Di * d.Hi * d.Wi;
+  auto fetch = [&](const Item& t) {
+    const bool live = (t.ph < p.nphase) & (items > 0);
+    const int ph_i = live ? t.ph : 0;
+    const int cc = t.chunk * 32;
+    const Phase& P = p.phase[ph_i];
+    const int dd = d.bd + d.td.off0 + d.td.offs * t.jd;
+    const bool first = cc < d.c1;
+    const float* src = first ? d.x1 : d.x2;
+    const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
+    const int coff = first ? cc : cc - d.c1;
+    const uint32_t nrec = tot1 * ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, nrec, 0x00020000);
+    const bool cok = live & ((cc + pq * 4) < d.Cin);
+    const uint32_t cb = (uint32_t)(coff + pq * 4) * 4u;
+#pragma unroll
+    for (int i = 0; i < F22_NX; ++i) {
+      const int lr = (prc[i] >> 12) & 0xfff, lc = prc[i] & 0xfff;
+      const int ih = (lr + P.dh0) * P.sh + P.ph, iw = (lc + P.dw0) * P.sw + P.pw;
+      const int nd = pnd[i] + dd;                      // n * Di + id
+      const int id = (prc[i] >> 24) + dd;
+      const bool ok = cok & ((pok >> i) & 1u) & ((unsigned)id < (unsigned)d.Di) & ((unsigned)ih < (unsigned)d.Hi) &
+                      ((unsigned)iw < (unsigned)d.Wi);
+      const uint32_t off = (uint32_t)((nd * d.Hi + ih) * d.Wi + iw) * ld * 4u + cb;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < F22_NX; ++i) {
+      const int v = min(v0 + (NT_ / 8) * i, vtrash);
+      const int row = (v * p.rowmagic) >> 16;
+      *reinterpret_cast<f32x4*>(Xs + buf + v * LD + row * p.rowpad + pq * 4) = rx[i];
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rsu =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
+  const int NT = d.Npad / 32;
+  const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
+  const uint32_t ulane = (uint32_t)(r * 3) * xi_stride + (uint32_t)nt0 * nt_stride + (uint32_t)lane * 16u;
+  auto load_u = [&](const Item& t, int kk, f32x4 (&ub)[3]) {
+    const int ph_i = t.ph < p.nphase ? t.ph : 0;  // (one item past the end is requested and never used)
+    const uint32_t base = (uint32_t)((ph_i * d.td.count + t.jd) * 9) * xi_stride + (uint32_t)(t.chunk * 4 + kk) * 1024u + ulane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, base + c * xi_stride, 0, 0));
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
+
+  auto kstep = [&](int buf, const int kk, const f32x4 (&ub)[3]) {
+    f32x4 R[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      R[j] = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) ? off_odd : 0) + (j >> 1) * LD + kk * 8);
+    if (r != 1) {  // wave-uniform: the middle Winograd row is the patch row itself
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        R[j] -= *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) ? off_odd : 0) + (j >> 1) * LD + kk * 8);
+    }
+    f32x4 v[3];
+    v[0] = R[0] - R[1];
+    v[1] = R[1];
+    v[2] = R[2] - R[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
+  };
+
+  f32x4 u0[3], u1[3];
+  Item cur_i = {0, 0, min(jd_lo, d.td.count - 1)}, nxt_i = cur_i;
+  fetch(cur_i);
+  load_u(cur_i, 0, u0);
+  stage(0);
+  __syncthreads();
+  for (int it = 0; it < items; ++it) {
+    const int cur = (it & 1) * FBUF, nxt = cur ^ FBUF;
+    advance(nxt_i);
+    fetch(nxt_i);
+    load_u(cur_i, 1, u1);
+    kstep(cur, 0, u0);
+    load_u(cur_i, 2, u0);
+    kstep(cur, 1, u1);
+    load_u(cur_i, 3, u1);
+    kstep(cur, 2, u0);
+    load_u(nxt_i, 0, u0);
+    kstep(cur, 3, u1);
+    stage(nxt);
+    cur_i = nxt_i;
+    __syncthreads();
+  }
+
+  // ---- output transform Y = A^T M A, A^T = [[1,1,0],[0,1,1]]: columns in registers, rows through LDS
+  float* ex = smem;  // [fm*2+fn][r 3][c' 2][q][lane]
+  {
+    const f32x16 T0v = acc[0] + acc[1];
+    const f32x16 T1v = acc[1] + acc[2];
+    float* e0 = ex + (((fm * 2 + fn) * 3 + r) * 2) * 16 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      e0[q * 64] = T0v[q];
+      e0[(16 + q) * 64] = T1v[q];
+    }
+  }
+  __syncthreads();
+  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
+  const int col_n = n0 + fn * 32 + col;
+  const bool colok = col_n < d.Cout;
+  const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
+  float ssum[F22_MAXSLOT][2];
+#pragma unroll
+  for (int s = 0; s < F22_MAXSLOT; ++s) ssum[s][0] = ssum[s][1] = 0.f;
+  // the wave's (tile group, channel group): output positions (ro, co) = r, and r + 3 for wave row 0
+  for (int pos = r; pos < 4; pos += 3) {
+    const int ro = pos >> 1, co = pos & 1;
+    const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 0.f : 1.f;   // rows: (1,1,0) / (0,1,1)
+    const float* e0 = ex + ((fm * 2 + fn) * 3 * 2 + co) * 16 * 64 + lane;
+    float t[3][16];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + bv;
+      const float v = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
+      const int m = fm * 32 + 8 * (q >> 2) + 4 * half + (q & 3);   // MFMA C row = tile
+      const int tv = tab[m], hwp = tab[2 * TB + m], sl = tab[TB + m];
+      const int oh = 2 * (hwp >> 16) + ro, ow = 2 * (hwp & 0xffff) + co;
+      const bool ok = colok & (tv >= 0) & (oh < d.Lh) & (ow < d.Lw);
+      if (ok) d.y[((int64_t)tv + (int64_t)ro * d.osh * d.Wy + co * d.osw) * d.ldy + col_n] = v;
+      if (d.stats_mode != 0) {
+        const float vs = ok ? v : 0.f;
+#pragma unroll
+        for (int s = 0; s < F22_MAXSLOT; ++s) {
+          ssum[s][0] += (s == sl) ? vs : 0.f;
+          ssum[s][1] += (s == sl) ? vs * vs : 0.f;
+        }
+      }
+    }
+  }
+  if (d.stats_mode != 0) {  // block-level sums per (slice slot, column): one atomic each
+    __syncthreads();
+    float* red = smem;       // [slot][wave 12][half][2][32]
+    const int nslot = min(sl_ - s0 + 1, F22_MAXSLOT);
+#pragma unroll
+    for (int s = 0; s < F22_MAXSLOT; ++s)
+      if (s < nslot) {
+        float* rp = red + (((s * 12 + wv) * 2 + half) * 2) * 32 + col;
+        rp[0] = ssum[s][0];
+        rp[32] = ssum[s][1];
+      }
+    __syncthreads();
+    for (int task = tid; task < nslot * 64; task += NT_) {
+      const int s = task >> 6, fq = (task >> 5) & 1, c = task & 31;
+      const int cn = n0 + fq * 32 + c;
+      const int slice = s0 + s, od = slice / d.N, n = slice - od * d.N;
+      if (cn < d.Cout && od < d.Ld) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int w6 = 0; w6 < 6; ++w6)        // the six (row, tile group) waves of channel group fq, both halves
+          for (int h = 0; h < 2; ++h) {
+            const float* rp = red + (((s * 12 + fq * 6 + w6) * 2 + h) * 2) * 32 + c;
+            a1 += rp[0];
+            a2 += rp[32];
+          }
+        double* st = d.stats + ((int64_t)n * d.Cout + cn) * 2;
+        atomicAdd(st, (double)a1);
+        if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
+      }
+    }
+  }
+}
+
+int f22_conflicts(int ntw, int RPf) {
+  int worst = 0;
+  for (int a = 0; a < ntw; ++a) {
+    int cnt[16] = {0};
+    for (int l = 0; l < 16; ++l) {
+      const int t = a + l, th = t / ntw, tw = t - th * ntw;
+      const int unit = ((tw * LD + th * 2 * RPf) / 4) & 15;
+      if (++cnt[unit] > worst) worst = cnt[unit];
+    }
+  }
+  return worst;
+}
+
+bool plan22_flat(const rehr_gather_gemm_desc& d, F22Params& p) {
+  if (!(d.flags & REHR_GG_FLAT8) || d.sd != 1) return false;
+  AxisPlan ah, aw;
+  if (!plan_axis(d.th, d.sh, d.bh, ah) || !plan_axis(d.tw, d.sw, d.bw, aw)) return false;
+  if (ah.nph != aw.nph) return false;
+  if (ah.nph == 2 && (d.osh != 1 || d.osw != 1 || d.obh || d.obw)) return false;
+  if (d.td.count < 1 || d.td.count > 3) return false;
+  if (d.Npad % 64 || d.Lh < 6 || d.Lw < 6 || d.Lw > 64 || d.Lh > 2048 || d.Ld > 127) return false;
+  if (d.Lh % 16 == 0 && d.Lw % 16 == 0) return false;      // whole regions: the region kernel stages less
+  constexpr int TB = 64;
+  p.d = d;
+  p.nth = (d.Lh + 1) / 2;
+  p.ntw = (d.Lw + 1) / 2;
+  p.tps = p.nth * p.ntw;
+  if ((int64_t)p.nth * 2 * p.ntw * 2 * 10 > (int64_t)d.Lh * d.Lw * 13) return false;
+  const int64_t ntiles = (int64_t)d.N * d.Ld * p.tps;
+  if (ntiles >= (1ll << 30) || ntiles < TB) return false;
+  p.ntiles = (int)ntiles;
+  // one 768-thread block per CU: below one full round of 64-tile blocks the padded region kernel (more, equally long
+  // blocks) fills the chip better (512->128 @12x12: 144 blocks here against 256 there, 1.21 vs 1.12 ms)
+  if ((ntiles + 63) / 64 * (d.Npad / 64) < 256) return false;
+  if ((TB - 2) / p.tps + 2 > F22_MAXSLOT) return false;
+  p.PH = 2 * p.nth + 1;
+  p.nev = p.ntw + 1;
+  p.PWs = 2 * p.ntw + 1;
+  const int trr = (TB - 2) / p.ntw + 2, sdiff = (TB - 2) / p.tps + 1;
+  p.rows = 2 * (trr - 1) + sdiff + 3;
+  if ((int64_t)p.rows * p.PWs * 8 > (int64_t)F22_NX * NT_) return false;
+  p.rowmagic = 65536 / p.PWs + 1;
+  for (int v = 0; v <= p.rows * p.PWs; ++v)
+    if (((v * p.rowmagic) >> 16) != v / p.PWs) return false;
+  int best = 1 << 30;
+  p.rowpad = 12;
+  for (int pad = 4; pad <= 64; pad += 4) {
+    const int c = f22_conflicts(p.ntw, p.PWs * LD + pad);
+    if (c < best) { best = c; p.rowpad = pad; }
+  }
+  p.RP = p.PWs * LD + p.rowpad;
+  p.kchunks = (d.Cin + 31) / 32;
+  p.nphase = ah.nph * aw.nph;
+  for (int i = 0; i < ah.nph; ++i)
+    for (int j = 0; j < aw.nph; ++j) {
+      Phase& P = p.phase[i * aw.nph + j];
+      P.sh = ah.stride; P.sw = aw.stride;
+      P.ph = ah.par[i]; P.pw = aw.par[j];
+      P.dh0 = ah.dmin[i]; P.dw0 = aw.dmin[j];
+    }
+  const int64_t need = (int64_t)p.nphase * d.td.count * 9 * d.Npad * p.kchunks * 32 * 4;
+  if (need >= (1ll << 32) - 64) return false;
+  p.up_bytes = (uint32_t)need;
+  const int64_t tot = (int64_t)d.N * d.Di * d.Hi * d.Wi * 4;
+  if (tot * d.ldx1 >= (1ll << 32) - 64 || (d.x2 && tot * d.ldx2 >= (1ll << 32) - 64)) return false;
+  if ((int64_t)d.N * d.Dy * d.Hy * d.Wy >= (1ll << 31) || d.Npad / 64 > 65535) return false;
+  const int64_t xfl = (int64_t)2 * (p.rows * p.RP + LD + 4), efl = (int64_t)4 * 3 * 2 * 16 * 64;
+  const int64_t rfl = (int64_t)F22_MAXSLOT * 12 * 2 * 2 * 32;
+  int64_t fl = xfl > efl ? xfl : efl;
+  if (rfl > fl) fl = rfl;
+  p.tab_off = (int)fl;
+  if ((fl + 3 * TB) * 4 > 160 * 1024) return false;
+  return true;
+}
+
 bool plan22(const rehr_gather_gemm_desc& d, W22Params& p) {
   if (d.sd != 1) return false;
   AxisPlan ah, aw;
@@ -352,11 +701,40 @@ bool plan22(const rehr_gather_gemm_desc& d, W22Params& p) {
 }  // namespace
 
 int64_t wino22_workspace_bytes(const rehr_gather_gemm_desc& d) {
+  F22Params f;
+  if (plan22_flat(d, f)) return (int64_t)f.up_bytes;
   W22Params p;
   return plan22(d, p) ? (int64_t)p.up_bytes : 0;
 }
 
+static int wino22_flat_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
+  F22Params p;
+  if (!plan22_flat(d, p)) return REHR_ENOSUP;
+  if (d.wino_ws_bytes < (int64_t)p.up_bytes || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;
+  p.up = d.wino_ws;
+  const int64_t total = (int64_t)p.nphase * d.td.count * d.Npad * p.kchunks * 32;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, p.kchunks);
+  const size_t smem = (size_t)(p.tab_off + 3 * 64) * sizeof(float);
+  static size_t attr_smem = 0;
+  if (smem > attr_smem) {
+    if (hipFuncSetAttribute((const void*)wino22_flat_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        hipSuccess)
+      return REHR_EHIP;
+    attr_smem = smem;
+  }
+  dim3 grid((unsigned)((p.ntiles + 63) / 64), d.Npad / 64, 1);
+  hipLaunchKernelGGL(wino22_flat_conv_kernel, grid, dim3(NT_), smem, stream, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
 int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
+  if (d.wino_ws) {
+    const int frc = wino22_flat_try(d, stream);
+    if (frc != REHR_ENOSUP) return frc;
+  }
   W22Params p;
   if (!d.wino_ws || !plan22(d, p)) return REHR_ENOSUP;
   if (d.wino_ws_bytes < (int64_t)p.up_bytes || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;

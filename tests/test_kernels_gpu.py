@@ -303,6 +303,29 @@ WINO22 = [  # transposed convs whose 2x2-tap stride phases / stride-2 input grad
 ]
 
 
+WINO22_FLAT = [  # small planes: the flattened-tile form of the F(2x2,2x2) kernel (forward phases + stride-2 input gradient)
+    (128, 128, (3, 4, 4), (1, 2, 2), (1, 1, 1), (32, 8, 12, 12)),  # the reference's 12 x 12 planes: 36 tiles per slice
+    (64, 128, (3, 4, 4), (1, 2, 2), (1, 1, 1), (12, 6, 24, 24)),   # 24 x 24 planes, rows of 12 tiles
+    (64, 128, (1, 4, 4), (1, 2, 2), (0, 1, 1), (56, 4, 13, 11)),   # odd extents, one depth tap, two channel tiles
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", WINO22_FLAT)
+def test_winograd22_flat_conv_transpose(Cin, Cout, K, stride, pad, dims):
+    """wino22_flat_conv_kernel behind ConvTranspose3d (4 output phases, SE statistics over blocks that span several
+    samples) and behind its input gradient (stride-2, 4-tap gather: four source parities), against fp64."""
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=290)
+    w = _mk(Cin, Cout, *K, seed=291) / (Cin * K[0] * 4) ** 0.5
+    b = _mk(Cout, seed=292)
+    aw, ab = _mk(Cout, Cout, 1, 1, 1, seed=293) / Cout ** 0.5, _mk(Cout, seed=294)
+    # (no activation here: with 10^7 outputs a few always sit within rounding of LeakyReLU's kink, and one flipped branch
+    # is a 2 % error of the input gradient's max norm in fp32 AND in the direct kernels -- not what this test is about)
+    _run(lambda x, w, b, aw, ab: ops.fused_conv3d(x, w, b, stride, pad, transposed=True, se=(aw, ab)),
+         lambda x, w, b, aw, ab: _se(F.conv_transpose3d(x, w, b, stride, pad), aw, ab),
+         [x, w, b, aw, ab], [True] * 5)
+
+
 @pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", WINO22)
 def test_winograd22_conv_transpose(Cin, Cout, K, stride, pad, dims):
     from rehrseg_amd import hip_backend
