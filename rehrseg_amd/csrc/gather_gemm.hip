@@ -469,6 +469,11 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
     const int src = wino_conv_split_try(descs, count, st);
     if (src != REHR_ENOSUP) return src;
   }
+  if (count > 1 && descs[0].wino_ws != nullptr && descs[0].td.count <= 3) {
+    // output phases of a transposed convolution on small planes: one grid of the flattened-tile F(2x2,2x2) kernel
+    const int frc = wino22_flat_multi_try(descs, count, st);
+    if (frc != REHR_ENOSUP) return frc;
+  }
   GGMulti pm;
   int n = 0;
   for (int i = 0; i < count; ++i) {

@@ -329,6 +329,12 @@ struct F22Params {
   const float* up;
   uint32_t up_bytes;
   int nth, ntw, tps, ntiles, PH, PWs, nev, RP, rowpad, rows, rowmagic, tab_off;
+  // parts > 1: the output phases of one transposed convolution in ONE grid (blockIdx.z = part; each part a single
+  // source phase = phase[part], its own weight panel and output offsets) -- 4 x 288 blocks as one 1152-block launch
+  // instead of four launches of 1.125 rounds each
+  int parts;
+  const float* s_up[MAXPH];
+  int s_obh[MAXPH], s_obw[MAXPH];
 };
 
 __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p) {
@@ -345,6 +351,10 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
   const int half = lane >> 5, col = lane & 31;
   const int nt0 = blockIdx.y * 2 + fn, n0 = blockIdx.y * 64;
   const int T0 = blockIdx.x * TB;
+  const int part = p.parts > 1 ? (int)blockIdx.z : 0;
+  const int obh = p.parts > 1 ? p.s_obh[part] : d.obh, obw = p.parts > 1 ? p.s_obw[part] : d.obw;
+  const float* const up = p.parts > 1 ? p.s_up[part] : p.up;
+  const int nphase = p.parts > 1 ? 1 : p.nphase;
   const int Tl = min(T0 + TB, p.ntiles) - 1;
   const int s0 = T0 / p.tps, sl_ = Tl / p.tps;
   const int G0 = s0 * p.PH + 2 * ((T0 - s0 * p.tps) / p.ntw);
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
     const int s = T / p.tps, tt = T - s * p.tps;
     const int th = tt / p.ntw, tw = tt - th * p.ntw;
     const int od = s / d.N, n = s - od * d.N;
-    tab[tid] = T < p.ntiles ? ((n * d.Dy + od * d.osd + d.obd) * d.Hy + 2 * th * d.osh + d.obh) * d.Wy + 2 * tw * d.osw + d.obw
+    tab[tid] = T < p.ntiles ? ((n * d.Dy + od * d.osd + d.obd) * d.Hy + 2 * th * d.osh + obh) * d.Wy + 2 * tw * d.osw + obw
                             : -1;
     tab[TB + tid] = min(s - s0, F22_MAXSLOT - 1);
     tab[2 * TB + tid] = (th << 16) | tw;
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
       if (od_b + dd >= 0 && od_a + dd < d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
     }
   }
-  const int items = p.nphase * p.kchunks * max(0, jd_hi - jd_lo + 1);
+  const int items = nphase * p.kchunks * max(0, jd_hi - jd_lo + 1);
   f32x4 rx[F22_NX];
   struct Item { int ph, chunk, jd; };
   auto advance = [&](Item& t) {
@@ -410,10 +420,10 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
   };
   const uint32_t tot1 = (uint32_t)d.N * d.Di * d.Hi * d.Wi;
   auto fetch = [&](const Item& t) {
-    const bool live = (t.ph < p.nphase) & (items > 0);
+    const bool live = (t.ph < nphase) & (items > 0);
     const int ph_i = live ? t.ph : 0;
     const int cc = t.chunk * 32;
-    const Phase& P = p.phase[ph_i];
+    const Phase& P = p.phase[part + ph_i];
     const int dd = d.bd + d.td.off0 + d.td.offs * t.jd;
     const bool first = cc < d.c1;
     const float* src = first ? d.x1 : d.x2;
@@ -445,12 +455,12 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
   };
 
   const __amdgpu_buffer_rsrc_t rsu =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(up), 0, p.up_bytes, 0x00020000);
   const int NT = d.Npad / 32;
   const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
   const uint32_t ulane = (uint32_t)(r * 3) * xi_stride + (uint32_t)nt0 * nt_stride + (uint32_t)lane * 16u;
   auto load_u = [&](const Item& t, int kk, f32x4 (&ub)[3]) {
-    const int ph_i = t.ph < p.nphase ? t.ph : 0;  // (one item past the end is requested and never used)
+    const int ph_i = t.ph < nphase ? t.ph : 0;  // (one item past the end is requested and never used)
     const uint32_t base = (uint32_t)((ph_i * d.td.count + t.jd) * 9) * xi_stride + (uint32_t)(t.chunk * 4 + kk) * 1024u + ulane;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -600,7 +610,7 @@ int f22_conflicts(int ntw, int RPf) {
   return worst;
 }
 
-bool plan22_flat(const rehr_gather_gemm_desc& d, F22Params& p) {
+bool plan22_flat(const rehr_gather_gemm_desc& d, F22Params& p, int parts = 1) {
   if (!(d.flags & REHR_GG_FLAT8) || d.sd != 1) return false;
   AxisPlan ah, aw;
   if (!plan_axis(d.th, d.sh, d.bh, ah) || !plan_axis(d.tw, d.sw, d.bw, aw)) return false;
@@ -620,7 +630,7 @@ bool plan22_flat(const rehr_gather_gemm_desc& d, F22Params& p) {
   p.ntiles = (int)ntiles;
   // one 768-thread block per CU: below one full round of 64-tile blocks the padded region kernel (more, equally long
   // blocks) fills the chip better (512->128 @12x12: 144 blocks here against 256 there, 1.21 vs 1.12 ms)
-  if ((ntiles + 63) / 64 * (d.Npad / 64) < 256) return false;
+  if ((ntiles + 63) / 64 * (d.Npad / 64) * parts < 256) return false;
   if ((TB - 2) / p.tps + 2 > F22_MAXSLOT) return false;
   p.PH = 2 * p.nth + 1;
   p.nev = p.ntw + 1;
@@ -639,6 +649,7 @@ bool plan22_flat(const rehr_gather_gemm_desc& d, F22Params& p) {
   }
   p.RP = p.PWs * LD + p.rowpad;
   p.kchunks = (d.Cin + 31) / 32;
+  p.parts = 1;
   p.nphase = ah.nph * aw.nph;
   for (int i = 0; i < ah.nph; ++i)
     for (int j = 0; j < aw.nph; ++j) {
@@ -707,6 +718,17 @@ int64_t wino22_workspace_bytes(const rehr_gather_gemm_desc& d) {
   return plan22(d, p) ? (int64_t)p.up_bytes : 0;
 }
 
+static bool f22_allow_smem(size_t smem) {   // the attribute only ever grows
+  static size_t attr_smem = 0;
+  if (smem > attr_smem) {
+    if (hipFuncSetAttribute((const void*)wino22_flat_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        hipSuccess)
+      return false;
+    attr_smem = smem;
+  }
+  return true;
+}
+
 static int wino22_flat_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   F22Params p;
   if (!plan22_flat(d, p)) return REHR_ENOSUP;
@@ -717,14 +739,51 @@ static int wino22_flat_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, p.kchunks);
   const size_t smem = (size_t)(p.tab_off + 3 * 64) * sizeof(float);
-  static size_t attr_smem = 0;
-  if (smem > attr_smem) {
-    if (hipFuncSetAttribute((const void*)wino22_flat_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
-        hipSuccess)
-      return REHR_EHIP;
-    attr_smem = smem;
-  }
+  if (!f22_allow_smem(smem)) return REHR_EHIP;
   dim3 grid((unsigned)((p.ntiles + 63) / 64), d.Npad / 64, 1);
+  hipLaunchKernelGGL(wino22_flat_conv_kernel, grid, dim3(NT_), smem, stream, p);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+// The output phases of one transposed convolution (same operands and lattice, different taps / output offsets / weight
+// scratch) in one grid of the flattened-tile kernel.  REHR_OK launched; REHR_ENOSUP not applicable.
+int wino22_flat_multi_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t stream) {
+  if (count < 2 || count > MAXPH) return REHR_ENOSUP;
+  F22Params p;
+  if (!ds[0].wino_ws || !plan22_flat(ds[0], p, count) || p.nphase != 1) return REHR_ENOSUP;
+  const Phase ph0 = p.phase[0];
+  const rehr_gather_gemm_desc& d0 = ds[0];
+  for (int i = 0; i < count; ++i) {
+    const rehr_gather_gemm_desc& d = ds[i];
+    F22Params q;
+    if (!d.wino_ws || ((uintptr_t)d.wino_ws & 15) || !plan22_flat(d, q, count) || q.nphase != 1 ||
+        d.wino_ws_bytes < (int64_t)q.up_bytes || q.up_bytes != p.up_bytes)
+      return REHR_ENOSUP;
+    if (d.x1 != d0.x1 || d.x2 != d0.x2 || d.Cin != d0.Cin || d.c1 != d0.c1 || d.ldx1 != d0.ldx1 || d.ldx2 != d0.ldx2 ||
+        d.Cout != d0.Cout || d.Npad != d0.Npad || d.y != d0.y || d.ldy != d0.ldy || d.N != d0.N || d.Ld != d0.Ld ||
+        d.Lh != d0.Lh || d.Lw != d0.Lw || d.Di != d0.Di || d.Hi != d0.Hi || d.Wi != d0.Wi || d.Dy != d0.Dy ||
+        d.Hy != d0.Hy || d.Wy != d0.Wy || d.osd != d0.osd || d.osh != d0.osh || d.osw != d0.osw || d.obd != d0.obd ||
+        d.bd != d0.bd || d.td.count != d0.td.count || d.td.off0 != d0.td.off0 || d.td.offs != d0.td.offs ||
+        d.bias != d0.bias || d.act != d0.act || d.slope != d0.slope || d.stats != d0.stats ||
+        d.stats_mode != d0.stats_mode || q.phase[0].sh != ph0.sh || q.phase[0].sw != ph0.sw)
+      return REHR_ENOSUP;
+    p.phase[i] = q.phase[0];
+    p.s_up[i] = d.wino_ws;
+    p.s_obh[i] = d.obh;
+    p.s_obw[i] = d.obw;
+  }
+  p.parts = count;
+  p.up = nullptr;
+  for (int i = 0; i < count; ++i) {
+    const int64_t total = (int64_t)ds[i].td.count * ds[i].Npad * p.kchunks * 32;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ds[i], ds[i].wino_ws, p.kchunks);
+  }
+  const size_t smem = (size_t)(p.tab_off + 3 * 64) * sizeof(float);
+  if (!f22_allow_smem(smem)) return REHR_EHIP;
+  dim3 grid((unsigned)((p.ntiles + 63) / 64), d0.Npad / 64, count);
   hipLaunchKernelGGL(wino22_flat_conv_kernel, grid, dim3(NT_), smem, stream, p);
   REHR_LAUNCH_CHECK();
   return REHR_OK;

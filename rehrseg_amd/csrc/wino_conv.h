@@ -9,6 +9,8 @@ int wino_conv_split_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t 
 // F(2x2,2x2) variant for 2-tap phases / stride-2 4-tap gathers (wino22_conv.hip)
 int64_t wino22_workspace_bytes(const rehr_gather_gemm_desc& d);
 int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
+// the output phases of one transposed convolution in one grid of the flattened-tile F(2x2,2x2) kernel
+int wino22_flat_multi_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t stream);
 // small-lattice variant with flattened tile numbering (wino_flat_conv.hip)
 int wino_weights_frag_launch(const rehr_gather_gemm_desc& d, int kchunks, hipStream_t stream);
 int64_t wino_flat_workspace_bytes(const rehr_gather_gemm_desc& d);

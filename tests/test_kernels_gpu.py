@@ -307,6 +307,7 @@ WINO22_FLAT = [  # small planes: the flattened-tile form of the F(2x2,2x2) kerne
     (128, 128, (3, 4, 4), (1, 2, 2), (1, 1, 1), (32, 8, 12, 12)),  # the reference's 12 x 12 planes: 36 tiles per slice
     (64, 128, (3, 4, 4), (1, 2, 2), (1, 1, 1), (12, 6, 24, 24)),   # 24 x 24 planes, rows of 12 tiles
     (64, 128, (1, 4, 4), (1, 2, 2), (0, 1, 1), (56, 4, 13, 11)),   # odd extents, one depth tap, two channel tiles
+    (96, 64, (3, 4, 4), (1, 2, 2), (1, 1, 1), (32, 4, 12, 12)),    # one channel tile: only the 4-phase grid fills the chip
 ]
 
 
@@ -324,6 +325,11 @@ def test_winograd22_flat_conv_transpose(Cin, Cout, K, stride, pad, dims):
     _run(lambda x, w, b, aw, ab: ops.fused_conv3d(x, w, b, stride, pad, transposed=True, se=(aw, ab)),
          lambda x, w, b, aw, ab: _se(F.conv_transpose3d(x, w, b, stride, pad), aw, ab),
          [x, w, b, aw, ab], [True] * 5)
+    if Cin == 96:   # the decoder's two-source form (virtual concat), phases in one grid
+        xa_, xb_ = x[:, :64].contiguous(), x[:, 64:].contiguous()
+        _run(lambda xa_, xb_, w, b: ops.fused_conv3d(xa_, w, b, stride, pad, x2=xb_, transposed=True),
+             lambda xa_, xb_, w, b: F.conv_transpose3d(torch.cat([xa_, xb_], 1), w, b, stride, pad),
+             [xa_, xb_, w, b], [True] * 4)
 
 
 @pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", WINO22)
