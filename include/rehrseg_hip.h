@@ -206,6 +206,9 @@ typedef struct {
 #define REHR_WGRAD_8WAVE 4
 /* bf16 weight gradient: the LDS brick kernel with eight waves per block (two per SIMD) instead of four */
 #define REHR_WGRAD_BRICK_8WAVE 8
+/* Winograd weight gradient: walk every output slice for every depth tap (default: a tap skips the slices whose source
+ * slice lies outside the volume; tests compare both) */
+#define REHR_WGRAD_NO_TAP_SKIP 16
 
 /* Mixed-precision weight gradient: l and g point at bf16 elements (ld* in elements, % 8 == 0; Ca, Cg % 8 == 0),
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 slabs and fp32 dst (the master-weight gradient).  dbias must

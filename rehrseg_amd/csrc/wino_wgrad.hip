@@ -47,7 +47,12 @@ struct WWParams {
   // width G*(Lw+2) -- a pure index map in the fetch; dY is zero in the gutters, so whatever the transform
   // multiplies it with drops out.  G = 0: plain lattice.
   int G, Lw2, nslices, rcp;
-  uint32_t rcp_ld;   // ceil(2^32 / Ld)
+  uint32_t rcp_ld;   // ceil(2^32 / Ld), or ceil(2^32 / N) when the slices are numbered depth-major (skip)
+  // skip: a depth tap walks only the output slices whose source slice exists (od + offset inside the volume) instead of
+  // multiplying zeros for the others -- 1/6 of the products at depth 4 with 3 taps.  The plain lattice walks od in
+  // [od_lo, od_hi); the side-by-side mode numbers its slices depth-major (od * N + n, N % G == 0) so that whole groups
+  // drop out.  bias_jd = the tap whose walk sees every slice (the bias gradient is a by-product of ONE tap's walk).
+  int skip, bias_jd;
   float* slabs;      // [splits][KD][16][Capad][Cgpad]
   float* slab_bias;  // [splits][Capad] or null: per-split column sums of dY (bias gradient)
 };
@@ -91,9 +96,22 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
   const int at = blockIdx.y / p.c_tiles, ct = blockIdx.y - at * p.c_tiles;
   const int jd = blockIdx.z;
   const int ca0 = at * (FA * WS * 32), cg0 = ct * (FB * 32);
-  const int it0 = split * p.items_per_split;
-  const int it1 = min(it0 + p.items_per_split, p.items);
-  const int nstages = it1 - it0;
+  const int doff = d.bd + d.td.off0 + d.td.offs * jd;
+  // output slices this tap reaches, and its share of the split-K walk
+  const int od_lo = p.skip ? max(0, -doff) : 0, od_hi = p.skip ? min(d.Ld, d.Dg - doff) : d.Ld;
+  const int nod = max(0, od_hi - od_lo);
+  int items_tap, g_lo = 0;
+  if constexpr (VIRT) {
+    g_lo = p.skip ? (od_lo * d.N) / p.G : 0;
+    const int g_hi = p.skip ? (od_hi * d.N) / p.G : (p.nslices + p.G - 1) / p.G;
+    items_tap = max(0, g_hi - g_lo) * p.nb_h * p.nb_w;
+  } else {
+    items_tap = d.N * nod * p.nb_h * p.nb_w;
+  }
+  const int ips = p.skip ? (items_tap + (int)gridDim.x - 1) / (int)gridDim.x : p.items_per_split;
+  const int it0 = split * ips;
+  const int it1 = min(it0 + ips, p.skip ? items_tap : p.items);
+  const int nstages = max(0, it1 - it0);
 
   // Z rows (A dY): (y0, y0+y1, y0-y1, -y1) -> ka*y0 + kb*y1, row 3 folded negated
   const float zka = (r == 3) ? 0.f : 1.f, zkb = (r == 0) ? 0.f : ((r == 2) ? -1.f : 1.f);
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
     int it = it0;
     f_bw = it % p.nb_w; it /= p.nb_w;
     f_bh = it % p.nb_h; it /= p.nb_h;
-    if constexpr (VIRT) { f_od = 0; f_n = it; } else { f_od = it % d.Ld; f_n = it / d.Ld; }
+    if constexpr (VIRT) { f_od = 0; f_n = g_lo + it; } else { const int nd = max(nod, 1); f_od = od_lo + it % nd; f_n = it / nd; }
   }
   auto advance = [&]() {
     --f_left;
@@ -140,12 +158,11 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
     if constexpr (VIRT) {
       f_n += h_end ? 1 : 0;
     } else {
-      const bool d_end = h_end & (f_od + 1 == d.Ld);
-      f_od = h_end ? (d_end ? 0 : f_od + 1) : f_od;
+      const bool d_end = h_end & (f_od + 1 == od_hi);
+      f_od = h_end ? (d_end ? od_lo : f_od + 1) : f_od;
       f_n += d_end ? 1 : 0;
     }
   };
-  const int doff = d.bd + d.td.off0 + d.td.offs * jd;
   auto fetch = [&](const int lo, const int hi, const int base) {  // pieces [lo, hi) of the cursor's item -> rx[i - base]
     const bool live = f_left > 0;
     const int oh0 = f_bh * RH, ow0 = f_bw * RW;
@@ -191,8 +208,14 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
         const int c = cvc - s_ * p.Lw2 - 1;
         const int slice = sg + s_;
         // slice / Ld: multiply-high by ceil(2^32 / Ld), exact below 65536 slices (planner); Ld = 1 has no 32-bit reciprocal
-        const int n = (d.Ld == 1) ? slice : (int)__umulhi((uint32_t)slice, p.rcp_ld);
-        const int od = slice - n * d.Ld;
+        int n, od;
+        if (p.skip) {   // depth-major numbering: od * N + n
+          od = (d.N == 1) ? slice : (int)__umulhi((uint32_t)slice, p.rcp_ld);
+          n = slice - od * d.N;
+        } else {
+          n = (d.Ld == 1) ? slice : (int)__umulhi((uint32_t)slice, p.rcp_ld);
+          od = slice - n * d.Ld;
+        }
         const bool sok = live & (cv >= 0) & (s_ < p.G) & (slice < p.nslices) & ((unsigned)c < (unsigned)d.Lw);
         if (isy) {
           const int gh = oh0 + row;
@@ -385,7 +408,7 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
     }
   }
 
-  if (p.slab_bias != nullptr && r == 1 && jd == 0 && ct == 0) {
+  if (p.slab_bias != nullptr && r == 1 && jd == p.bias_jd && ct == 0) {
 #pragma unroll
     for (int fa = 0; fa < FA; ++fa) {
       const float t = bsum[fa] + __shfl_xor(bsum[fa], 32, 64);
@@ -543,6 +566,17 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   }
   if (items >= (1ll << 30) || items < 4) return false;
   p.items = (int)items;
+  // depth-tap skipping needs one tap that reaches every output slice (it carries the bias gradient)
+  p.skip = 0;
+  p.bias_jd = 0;
+  for (int j = 0; j < d.td.count && !(d.flags & REHR_WGRAD_NO_TAP_SKIP); ++j) {
+    const int dd = d.bd + d.td.off0 + d.td.offs * j;
+    if (dd >= 0 && d.Dg - dd >= d.Ld) { p.skip = 1; p.bias_jd = j; break; }   // od_lo == 0 and od_hi == Ld
+  }
+  if (p.G != 0) {
+    if (p.skip && d.N % p.G == 0) p.rcp_ld = d.N > 1 ? (uint32_t)((0x100000000ull + d.N - 1) / d.N) : 0u;
+    else { p.skip = 0; p.bias_jd = 0; }
+  }
   p.fa = (d.Ca <= 32) ? 1 : 2;  // 32-channel sides take a single 32-wide group
   p.fb = (d.Cg <= 32) ? 1 : 2;
   // two 64 x 32 blocks per CU instead of one 64 x 64 block (REHR_WGRAD_TWO_PER_CU): a second wave per SIMD fills the

@@ -157,6 +157,7 @@ USE_WINOGRAD_WGRAD = True
 USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps
 USE_WGRAD_BRICK_8WAVE = True   # mixed precision: the brick weight-gradient kernel with eight waves per block
 USE_HALO_8WAVE = True   # mixed precision: the halo-brick kernel with eight waves per block
+USE_WGRAD_TAP_SKIP = True   # Winograd weight gradient: a depth tap walks only the slices whose source slice exists
 USE_WGRAD_8WAVE = True   # Winograd weight gradient: the 64 x 64 block as 8 waves (two per SIMD)
 USE_WGRAD_TWO_PER_CU = False  # Winograd weight gradient: two 64 x 32 blocks per CU for the >= 64-channel layers
 USE_W32_TWO_PER_CU = False # fp32 32-channel-tile Winograd kernel: two 512-thread blocks per CU (False: one of 1024)
@@ -297,7 +298,8 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     d.accumulate = int(accumulate)
     d.dbias = _ptr(dbias)
     d.flags = ((0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT) | (L.WGRAD_TWO_PER_CU if USE_WGRAD_TWO_PER_CU else 0) |
-               (L.WGRAD_8WAVE if USE_WGRAD_8WAVE else 0) | (L.WGRAD_BRICK_8WAVE if USE_WGRAD_BRICK_8WAVE else 0))
+               (L.WGRAD_8WAVE if USE_WGRAD_8WAVE else 0) | (L.WGRAD_BRICK_8WAVE if USE_WGRAD_BRICK_8WAVE else 0) |
+               (0 if USE_WGRAD_TAP_SKIP else L.WGRAD_NO_TAP_SKIP))
     lib = L.load()
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
     if bf16:

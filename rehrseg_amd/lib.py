@@ -21,6 +21,7 @@ WGRAD_DIRECT = 1  # rehr_wgrad_desc.flags
 WGRAD_TWO_PER_CU = 2
 WGRAD_8WAVE = 4
 WGRAD_BRICK_8WAVE = 8
+WGRAD_NO_TAP_SKIP = 16
 GG_Y_F32 = 1      # rehr_gather_gemm_desc.flags
 GG_NO_HALO = 2
 GG_WINO_8WAVE = 4

@@ -596,6 +596,38 @@ def test_winograd_wgrad_two_per_cu_variant():
     torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("dims,Ca,Cg,K", [((16, 4, 12, 12), 128, 64, (3, 3, 3)),   # side-by-side mode, depth-major groups
+                                          ((2, 4, 24, 32), 64, 64, (3, 3, 3)),     # plain lattice, od range per tap
+                                          ((3, 2, 16, 16), 64, 128, (3, 3, 3)),    # depth 2: the outer taps see one slice
+                                          ((20, 4, 12, 12), 64, 64, (3, 3, 3))])   # N % 8 != 0: no skipping side by side
+def test_winograd_wgrad_tap_skip(dims, Ca, Cg, K):
+    """Depth taps that skip the output slices without a source slice (REHR_WGRAD_NO_TAP_SKIP off) against the full walk:
+    the skipped products are zeros, so weight and bias gradients agree to summation order; and against fp64."""
+    from rehrseg_amd import hip_backend as hb
+    N, D, H, W = dims
+    x = _mk(N, Cg, D, H, W, seed=171).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    dy = _mk(N, Ca, D, H, W, seed=172).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = _mk(Ca, Cg, *K, seed=173).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    saved = hb.USE_WGRAD_TAP_SKIP
+    try:
+        out = {}
+        for flag in (False, True):
+            hb.USE_WGRAD_TAP_SKIP = flag
+            before = hb.wino_wgrad_launches
+            out[flag] = ops.conv_wgrad(dy, x, None, w, cfg, True)
+            assert hb.wino_wgrad_launches - before == 1
+    finally:
+        hb.USE_WGRAD_TAP_SKIP = saved
+    _close(out[True][0], out[False][0].double().cpu(), 1e-5)   # (of the tensor's max: only the summation order differs)
+    _close(out[True][1], out[False][1].double().cpu(), 1e-5)
+    xr, wr = x.double().cpu().requires_grad_(), w.double().cpu().requires_grad_()
+    br = torch.zeros(Ca, dtype=torch.float64, requires_grad=True)
+    rw, rb = torch.autograd.grad(F.conv3d(xr, wr, br, 1, 1), [wr, br], dy.double().cpu())
+    _close(out[True][0], rw)
+    _close(out[True][1], rb)
+
+
 def test_winograd_wgrad_eight_wave_variant():
     """REHR_WGRAD_8WAVE (the 64 x 64 block as two wave sets, two waves per SIMD) against the four-wave block: the same
     products in the same order per accumulator -> the same bits."""
