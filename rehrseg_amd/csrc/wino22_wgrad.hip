@@ -52,9 +52,16 @@ __global__ __launch_bounds__(NTH) void wino22_wgrad_kernel(const WW22Params p) {
   const int ph_i = z / d.td.count, jd = z - ph_i * d.td.count;
   const Phase22& P = p.phase[ph_i];
   const int ca0 = at * 64, cg0 = ct * 64;
-  const int it0 = split * p.items_per_split;
-  const int it1 = min(it0 + p.items_per_split, p.items);
-  const int nstages = it1 - it0;
+  // a depth tap walks only the output slices whose source slice exists (unless REHR_WGRAD_NO_TAP_SKIP)
+  const bool skip = !(d.flags & REHR_WGRAD_NO_TAP_SKIP);
+  const int doff_ = d.bd + d.td.off0 + d.td.offs * jd;
+  const int od_lo = skip ? max(0, -doff_) : 0, od_hi = skip ? min(d.Ld, d.Dg - doff_) : d.Ld;
+  const int nod = max(0, od_hi - od_lo);
+  const int items_tap = d.N * nod * p.nb_h * p.nb_w;
+  const int ips = skip ? (items_tap + (int)gridDim.x - 1) / (int)gridDim.x : p.items_per_split;
+  const int it0 = split * ips;
+  const int it1 = min(it0 + ips, skip ? items_tap : p.items);
+  const int nstages = max(0, it1 - it0);
 
   // Z rows (A x): (x0, x0+x1, x1); V rows (B^T d): (d0-d1, d1, d2-d1)
   const float zka = (r == 2) ? 0.f : 1.f, zkb = (r == 0) ? 0.f : 1.f;
@@ -72,8 +79,9 @@ __global__ __launch_bounds__(NTH) void wino22_wgrad_kernel(const WW22Params p) {
     int it = it0;
     s_bw = it % p.nb_w; it /= p.nb_w;
     s_bh = it % p.nb_h; it /= p.nb_h;
-    s_od = it % d.Ld;
-    s_n = it / d.Ld;
+    const int nd = max(nod, 1);
+    s_od = od_lo + it % nd;
+    s_n = it / nd;
   }
   auto fetch = [&](int st) {
     const bool live = st < nstages;
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(NTH) void wino22_wgrad_kernel(const WW22Params p) {
       s_bw = 0;
       if (++s_bh == p.nb_h) {
         s_bh = 0;
-        if (++s_od == d.Ld) { s_od = 0; ++s_n; }
+        if (++s_od == od_hi) { s_od = od_lo; ++s_n; }
       }
     }
     const int oh0 = bh_ * RH, ow0 = bw_ * RW;
