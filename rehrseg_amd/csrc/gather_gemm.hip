@@ -464,8 +464,9 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
       return REHR_EINVAL;  // (y may differ: split-K partials go to separate slabs)
   }
   hipStream_t st = (hipStream_t)stream;
-  if (count > 1 && descs[0].td.count > 3 && descs[0].wino_ws != nullptr) {
-    // tap-range parts of a split-K launch with many depth taps: all parts in one Winograd grid, or none
+  if (count > 1 && descs[0].wino_ws != nullptr && (descs[0].td.count > 3 || descs[0].td.count == 1)) {
+    // tap-range parts of a split-K launch (many depth taps; or the single depth taps of a layer whose plain Winograd
+    // grid would leave half the chip idle): all parts in one Winograd grid, or none
     const int src = wino_conv_split_try(descs, count, st);
     if (src != REHR_ENOSUP) return src;
   }

@@ -222,6 +222,9 @@ def _thin5_f32(be, x, w, cfg: ConvCfg, shape=None):
             be.thin5_supported(tuple(shape if shape is not None else x.shape), tuple(w.shape), cfg.pad, torch.float32))
 
 
+WINO_TAP_SPLIT = True   # see _tap_split (tests and A/B runs switch it off)
+
+
 def _sub_taps(t, a, b):
     """taps [a, b) of one axis' arithmetic tap description."""
     cnt, off0, offs, k0, ks = t
@@ -240,6 +243,11 @@ def _tap_split(lattice, N, Npad, taps, Cin):
         # unit-stride 3x3 taps: leave lattices the Winograd kernels accept (8x16-output regions, <= 1.3x
         # padding; librehrseg's wino_workspace_bytes applies the same rule) to them
         Lh, Lw = lattice[1], lattice[2]
+        if (WINO_TAP_SPLIT and taps[0][0] == 3 and Lh % 16 == 0 and Lw % 16 == 0 and Npad % 64 == 0 and
+                (Lh // 16) * (Lw // 16) * lattice[0] * N * (Npad // 64) <= 160):
+            # whole 16x16 regions but at most ~half a chip of big-tile Winograd blocks (nnU-Net's 16^3 stage: 128): the
+            # three depth taps as three parts of ONE Winograd grid (wino_conv_split_try), a third of the K loop each
+            return [[_sub_taps(taps[0], a, a + 1), taps[1], taps[2]] for a in range(3)]
         if Lh >= 8 and Lw >= 8 and (-(-Lh // 8) * 8) * (-(-Lw // 16) * 16) * 100 <= Lh * Lw * 134:
             return None
         # ... and small planes the flattened-tile Winograd kernel takes (16..63 tiles per slice, >= 64 tiles)

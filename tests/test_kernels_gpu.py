@@ -265,6 +265,21 @@ def test_split_k_many_depth_taps_winograd():
     assert hip_backend.wino_wgrad_launches - before_w == 1
 
 
+def test_winograd_depth_tap_split_half_filled_grid():
+    """nnU-Net's 16^3 stage (2 x 256 x 16^3: 128 big-tile Winograd blocks on 256 CUs): the three depth taps as three
+    parts of one Winograd grid + the combine (bias, InstanceNorm statistics), forward and input gradient."""
+    from rehrseg_amd import hip_backend
+    x = _mk(2, 128, 16, 16, 16, seed=263)
+    w = _mk(128, 128, 3, 3, 3, seed=264) / (128 * 27) ** 0.5
+    b, ga, be = _mk(128, seed=265), _mk(128, seed=266), _mk(128, seed=267)
+    assert ops._tap_split((16, 16, 16), 2, 128, [ops.full_taps(3)] * 3, 128) is not None
+    before = hip_backend.wino_launches
+    _run(lambda x, w, b, ga, be: ops.fused_conv3d(x, w, b, 1, 1, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
+         lambda x, w, b, ga, be: F.leaky_relu(F.instance_norm(F.conv3d(x, w, b, 1, 1), weight=ga, bias=be), 0.01),
+         [x, w, b, ga, be], [True, True, False, True, True])
+    assert hip_backend.wino_launches - before == 6   # 3 forward parts + 3 input-gradient parts
+
+
 def test_split_k_low_resolution_stage_with_instnorm():
     """nnU-Net bottom stage (4^3 voxels, hundreds of channels): 6 tap ranges in one grid, the combine carries
     bias + InstanceNorm statistics; the input gradient takes the same route.  (8^3 stages go to the

@@ -1,5 +1,5 @@
 """Per-launch times of the matrix-core kernels in one training step, by layer shape (GPU box):
-    python tools/layer_times.py flavr_ref|flavr
+    python tools/layer_times.py flavr_ref|flavr|seg
 Uses hip_backend's event timing (the same events bench.py's roofline line sums per family)."""
 import collections, os, sys
 import torch
@@ -14,14 +14,29 @@ which = sys.argv[1] if len(sys.argv) > 1 else "flavr_ref"
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
 torch.manual_seed(0)
-if which == "flavr_ref":
+if which == "seg":   # bench.py's cfg-3 workload
+    sys.path.insert(0, root)
+    import bench
+    from rehrseg_amd.utils.seg_utils import _build_loss
+    model = bench.build_seg_model(dev)
+    x = torch.randn(2, 1, 128, 128, 128, generator=g).to(dev)
+    lab_lr = torch.randint(0, 2, (2, 1, 128, 128, 128), generator=g).float().to(dev)
+    lab_hr = torch.randint(0, 2, (2, 1, 512, 128, 128), generator=g).float().to(dev)
+    ce = _build_loss()
+elif which == "flavr_ref":
     model, unc = UNet_3D_3D(2, "unet_18", 4, 4, use_uncertainty=True).to(dev), True
     x, hr = torch.rand(32, 2, 4, 96, 96, generator=g).to(dev), torch.rand(32, 2, 16, 96, 96, generator=g)
 else:   # bench.py's headline workload (BASELINE cfg-2)
     model = UNet_3D_3D(img_channels=1, block="unet_18", n_inputs=128, n_outputs=4).to(dev)
     x, tgt = torch.rand(1, 1, 128, 128, 128, generator=g).to(dev), torch.rand(1, 1, 4, 128, 128, generator=g).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.99), fused=True)
-if which == "flavr_ref":
+if which == "seg":
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out, out_up = model(x)
+        (ce(out, lab_lr) + ce(out_up, lab_hr)).backward()
+        opt.step()
+elif which == "flavr_ref":
     hr[:, 1:] = (hr[:, 1:] > 0.5).float()
     hr = hr.to(dev)
     l1, bd = torch.nn.L1Loss(), BCEDiceLoss(1.0, 1.0)
