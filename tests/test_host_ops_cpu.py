@@ -232,7 +232,9 @@ def test_split_k_many_depth_taps(emu):
 def test_split_k_low_resolution_stage(emu):
     """4^3-voxel stage (too small even for the flattened-tile Winograd kernel): the taps are split over (depth, row)
     ranges for forward and input gradient, the combine carries the InstanceNorm statistics."""
-    assert ops._tap_split((4, 32, 32), 2, 64, [ops.full_taps(3)] * 3, 128) is None   # Winograd-sized lattice
+    assert ops._tap_split((4, 24, 40), 2, 64, [ops.full_taps(3)] * 3, 128) is None   # Winograd-sized lattice
+    halfgrid = ops._tap_split((4, 32, 32), 2, 64, [ops.full_taps(3)] * 3, 128)       # ... that fills 32 of 256 CUs:
+    assert halfgrid is not None and [t[0][0] for t in halfgrid] == [1, 1, 1]         # its depth taps as 3 parts
     assert ops._tap_split((4, 12, 12), 32, 512, [ops.full_taps(3)] * 3, 512) is None  # flattened-tile Winograd
     assert ops._tap_split((4, 8, 8), 2, 64, [ops.full_taps(3)] * 3, 128) is not None  # too few tiles for it
     parts = ops._tap_split((4, 4, 4), 2, 64, [ops.full_taps(3)] * 3, 128)
