@@ -243,7 +243,7 @@ def _tap_split(lattice, N, Npad, taps, Cin):
         # unit-stride 3x3 taps: leave lattices the Winograd kernels accept (8x16-output regions, <= 1.3x
         # padding; librehrseg's wino_workspace_bytes applies the same rule) to them
         Lh, Lw = lattice[1], lattice[2]
-        if (WINO_TAP_SPLIT and taps[0][0] == 3 and Lh % 16 == 0 and Lw % 16 == 0 and Npad % 64 == 0 and
+        if (WINO_TAP_SPLIT and taps[0][0] == 3 and lattice[0] >= 2 and Lh % 16 == 0 and Lw % 16 == 0 and Npad % 64 == 0 and
                 (Lh // 16) * (Lw // 16) * lattice[0] * N * (Npad // 64) <= 160):
             # whole 16x16 regions but at most ~half a chip of big-tile Winograd blocks (nnU-Net's 16^3 stage: 128): the
             # three depth taps as three parts of ONE Winograd grid (wino_conv_split_try), a third of the K loop each
