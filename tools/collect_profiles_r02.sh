@@ -14,6 +14,8 @@ done
 python3 $R/bench.py --workload cfg5 --steps 20 $B > $O/b_cfg5.log 2>&1 || exit 1; tail -1 $O/b_cfg5.log > $O/b_cfg5.json
 python3 $R/tools/bench_thin5.py > $O/thin5_bf16.txt 2>&1
 python3 $R/tools/bench_feed.py 2>&1 | grep -v "image shape\|Total subjects\|libdrm" > $O/feed_bench.txt
+python3 $R/tools/bench_ref_layers.py > $O/ref_layers.txt 2>&1
+for w in flavr_ref flavr seg; do python3 $R/tools/layer_times.py $w > $O/layers_$w.txt 2>&1; done
 fi
 if [ "$PART" = all ] || [ "$PART" = stats ]; then
 for w in flavr seg cfg4 flavr_ref; do

@@ -20,5 +20,7 @@ if [ -f $O/f_stream/f_counter_collection.csv ]; then
   cp $O/stream_algo.json $P/r02_stream_algorithmic.json
   python3 tools/pmc_hbm.py $O/t_stream/t_kernel_trace.csv $O/f_stream/f_counter_collection.csv $O/w_stream/w_counter_collection.csv $P/r02_pmc_hbm_stream.json --algo $O/stream_algo.json
 fi
+for w in flavr_ref flavr seg; do [ -f $O/layers_$w.txt ] && grep -v 'amdgpu\|Warning' $O/layers_$w.txt > $P/r02_layer_times_$w.txt; done
+[ -f $O/ref_layers.txt ] && grep -v amdgpu $O/ref_layers.txt > $P/r02_ref_shape_layers.txt
 for c in 2 3; do [ -f gpurun_out/parity_cfg$c.json ] && cp gpurun_out/parity_cfg$c.json $P/r02_parity_cfg$c.json; done
 ls $P | grep r02
