@@ -1336,9 +1336,13 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel
   auto issue_reads = [&](int buf, const int m, const int kkl) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#ifdef W3P_DBG_NOLDS    // (timing diagnostics only: wrong results)
+      ra[j] = f32x4{(float)lane, 1.f, 2.f, (float)j}; rb[j] = f32x4{2.f, (float)lane, 1.f, (float)m}; (void)buf; (void)kkl;
+#else
       const int o = buf + m * GOFF + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8;
       ra[j] = *reinterpret_cast<const f32x4*>(xa + o);
       rb[j] = *reinterpret_cast<const f32x4*>(xb + o);
+#endif
     }
   };
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1404,7 +1408,9 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel
     // the next item's patch is complete and nobody reads the current one any more (step 3's fragments are in V1):
     // the barrier goes HERE, so that the next item's first fragments are read and combined behind step 3's MFMAs
     W3P_FENCE();
+#ifndef W3P_DBG_NOBAR   // (timing diagnostics only: wrong results)
     __syncthreads();
+#endif
     // step 3: (group 1, k-group 1); u1 is released behind it
     W3P_FENCE();
     issue_reads(nxt, 0, 0);
