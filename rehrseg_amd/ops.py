@@ -313,7 +313,8 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     # 40 tiles x 27 taps x 320 channels): split the taps over S partial launches in one grid and combine the
     # slabs in a fixed order (the combine carries bias, activation and the statistics epilogue).
     bf16 = x1.dtype == torch.bfloat16   # (the split-K combine kernels are fp32; bf16 layers run unsplit)
-    parts = _tap_split(out_dims, N, Npad, taps, Cin) if (cfg.stride == (1, 1, 1) or K[0] >= 8) and not bf16 else None
+    # (strided convolutions too: nnU-Net's 8^3 -> 4^3 stage is 10 blocks walking 8640 products each without it)
+    parts = _tap_split(out_dims, N, Npad, taps, Cin) if not bf16 else None
     if parts is not None and Cout % 4 == 0:
         S = len(parts)
         slabs = be.new_act(S * N, Cout, *out_dims, like=x1)

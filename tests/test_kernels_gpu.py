@@ -265,6 +265,17 @@ def test_split_k_many_depth_taps_winograd():
     assert hip_backend.wino_wgrad_launches - before_w == 1
 
 
+def test_split_k_strided_low_resolution_stage():
+    """nnU-Net's last down-sampling convs (stride 2 into 8^3 / 4^3 voxels, 256-320 channels): tap ranges in one grid."""
+    for Cin, Cout, D in ((256, 320, 16), (320, 320, 8)):
+        x = _mk(2, Cin, D, D, D, seed=271)
+        w = _mk(Cout, Cin, 3, 3, 3, seed=272) / (Cin * 27) ** 0.5
+        b, ga, be = _mk(Cout, seed=273), _mk(Cout, seed=274), _mk(Cout, seed=275)
+        _run(lambda x, w, b, ga, be: ops.fused_conv3d(x, w, b, 2, 1, inorm=(ga, be), act=ops.ACT_LRELU, slope=0.01),
+             lambda x, w, b, ga, be: F.leaky_relu(F.instance_norm(F.conv3d(x, w, b, 2, 1), weight=ga, bias=be), 0.01),
+             [x, w, b, ga, be], [True, True, False, True, True])
+
+
 def test_winograd_depth_tap_split_half_filled_grid():
     """nnU-Net's 16^3 stage (2 x 256 x 16^3: 128 big-tile Winograd blocks on 256 CUs): the three depth taps as three
     parts of one Winograd grid + the combine (bias, InstanceNorm statistics), forward and input gradient."""
