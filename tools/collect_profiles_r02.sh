@@ -32,6 +32,7 @@ for w in flavr seg; do
   prof --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w_$w -o w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/w_$w.log 2>&1 || exit 1
   prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_$w -o m -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_$w.log 2>&1 || exit 1
 done
+prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_flavr_ref -o m -- python3 $R/bench.py --workload flavr_ref --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_flavr_ref.log 2>&1 || exit 1
 prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_cfg5 -o m -- python3 $R/bench.py --workload cfg5 --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_cfg5.log 2>&1 || exit 1
 prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_seg_bf16 -o m -- python3 $R/bench.py --workload seg --precision bf16 --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_seg_bf16.log 2>&1 || exit 1
 fi

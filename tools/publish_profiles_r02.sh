@@ -13,7 +13,7 @@ done
 for w in flavr seg; do
   [ -f $O/f_$w/f_counter_collection.csv ] && python3 tools/pmc_hbm.py $O/t_$w/t_kernel_trace.csv $O/f_$w/f_counter_collection.csv $O/w_$w/w_counter_collection.csv $P/r02_pmc_hbm_$w.json
 done
-for w in flavr seg cfg5 seg_bf16; do
+for w in flavr seg cfg5 seg_bf16 flavr_ref; do
   [ -f $O/m_$w/m_counter_collection.csv ] && python3 tools/pmc_mfma.py $O/m_$w/m_counter_collection.csv $O/m_$w/m_kernel_trace.csv $P/r02_pmc_mfma_$w.json
 done
 if [ -f $O/f_stream/f_counter_collection.csv ]; then
