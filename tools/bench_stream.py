@@ -94,6 +94,16 @@ def main():
     add("seg_loss_fwd", (2, 2, 512, 128, 128), 4 * lg.numel() + 4 * tgt.numel(), lambda: hb.seg_loss_fwd(lg, tgt, None))
     add("seg_loss_bwd", (2, 2, 512, 128, 128), 8 * lg.numel() + 4 * tgt.numel(),
         lambda: hb.seg_loss_bwd(lg, tgt, None, st, 1.0, 1.0, 1e-5, False, go))
+    # UASR head of the reference-shape step (32 x 4 slices of 96 x 96, K = 16 candidate pairs)
+    om = act_t((32, 128, 1, 96, 96))
+    ue = act_t((32, 64, 1, 96, 96))
+    wu, bu = torch.randn(16, device=dev), torch.randn(1, device=dev)
+    uo, uu = hb.uasr_mix_fwd(om, ue, wu, bu, 4)
+    go_, gu_ = torch.randn_like(uo), torch.randn_like(uu)
+    vs = 32 * 4 * 96 * 96   # voxel-slices
+    add("uasr_mix_fwd", (32, 192, 1, 96, 96), vs * (12 * 16 + 12), lambda: hb.uasr_mix_fwd(om, ue, wu, bu, 4))
+    add("uasr_mix_bwd", (32, 192, 1, 96, 96), vs * (24 * 16 + 24), lambda: hb.uasr_mix_bwd(om, ue, wu, bu, go_, gu_, 4))
+    del om, ue, uo, uu, go_, gu_
     if args.json:
         json.dump({"peak_spec_TBps": 8.0, "peak_measured_copy_TBps": 6.29, "rows": rows}, open(args.json, "w"), indent=1)
 
