@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256 * NFM, NFM == 1 ? 2 : 1) void wino_flat8_conv_k
   const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
   // per-q tile facts of this lane (same for both channel groups)
   int yv[16];
-  uint32_t okbits = 0, slots = 0;   // 16 x 1 bit, 16 x 2-bit slot DELTA is not enough: keep the slot in 3 bits x 16 = 2 words
-  uint32_t slots_hi = 0;
+  uint32_t okbits = 0;                  // 16 x 1 bit: the tile exists and the pixel lies inside the lattice
+  uint32_t slots = 0, slots_hi = 0;     // 16 x 4 bits: statistics slot (slice relative to the block's first) per value
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int m = fm * 32 + 8 * (q >> 2) + 4 * half + (q & 3);   // MFMA C row = tile
