@@ -22,10 +22,19 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return None
 
     def create_module(self, spec):
-        return importlib.import_module("rehrseg_amd." + spec.name)  # ImportError for names the mirror lacks
+        real = importlib.import_module("rehrseg_amd." + spec.name)  # ImportError for names the mirror lacks
+        # importlib's module_from_spec overwrites __spec__ / __loader__ of whatever create_module returns with the
+        # alias spec; the real module must keep its own (its lazy relative imports resolve against
+        # __spec__.parent == __package__ == "rehrseg_amd.<...>").  exec_module puts them back.
+        self._real[real.__name__] = (real.__spec__, real.__loader__)
+        return real
 
     def exec_module(self, module):
-        pass
+        spec, loader = self._real.pop(module.__name__, (None, None))
+        if spec is not None:
+            module.__spec__, module.__loader__ = spec, loader
+
+    _real = {}
 
 
 _finder = _AliasFinder()

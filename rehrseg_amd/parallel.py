@@ -87,9 +87,14 @@ class PatchParallel:
             for b in module.buffers():
                 dist.broadcast(b.data, src=0, group=process_group)
 
-    def _reset_step(self):
+    def _reset_step(self, uses=True):
+        """uses=False keeps the forward use counts: the reference's loops clear gradients AFTER the forward
+        (`loss = ...; opt.zero_grad(); loss.backward()`, train_all.py:135-137, 553-555), and the counts recorded
+        during that forward decide whether the weight-gradient kernels may write in place."""
         self._written = set()                                   # ids of parameters a kernel wrote directly
-        self._uses = {}                                         # id -> forward uses in this step
+        if uses:
+            self._uses = {}                                     # id -> forward uses since the last backward
+            self._in_backward = False
         self._ready = [set() for _ in self.buckets]             # per bucket: ids whose gradient is complete
         self._launched = [False] * len(self.buckets)
         self._works = []
@@ -130,11 +135,15 @@ class PatchParallel:
 
     # ---- direct gradient writes (see rehrseg_amd.ops._direct_grad)
     def note_use(self, p):
+        if self._in_backward:                                   # first forward use after a backward: a new step
+            self._uses.clear()
+            self._in_backward = False
         self._uses[id(p)] = self._uses.get(id(p), 0) + 1
 
     def may_write(self, p):
         """A kernel may overwrite p.grad only if this is the weight's single use in the step and nothing
         has been written yet (otherwise autograd's accumulation is the only correct route)."""
+        self._in_backward = True
         return self._uses.get(id(p), 0) == 1 and id(p) not in self._written
 
     def was_written(self, p):
@@ -153,7 +162,7 @@ class PatchParallel:
             p.grad = self._view[id(p)]
         for p in self._steal:
             p.grad = None
-        self._reset_step()
+        self._reset_step(uses=False)                            # may run between forward and backward
 
     def reduce_gradients(self):
         """Sum over ranks, divide by world size; returns after the exchange completed.
@@ -164,6 +173,7 @@ class PatchParallel:
             # single rank: handed-over gradients stay where autograd put them (the optimizer reads p.grad)
             self._written.clear()
             self._uses.clear()
+            self._in_backward = False
             return
         for i in range(len(self.buckets)):
             if not self._launched[i]:

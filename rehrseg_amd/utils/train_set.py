@@ -311,6 +311,13 @@ class _DeviceSet(torch.utils.data.Dataset):
         return self._run([self._plan(i) for i in indices])
 
     def __getitem__(self, i):
+        if torch.utils.data.get_worker_info() is not None:
+            # the reference's stage-2 loader forks 4 workers (train_all.py:502-509); these data sets live on the GPU
+            # and launch kernels, which a forked worker must not do
+            raise hb.L.RehrsegHipError(
+                "rehrseg_amd data sets keep their volumes in HBM and cut patches with HIP kernels: use them from the "
+                "training process (DataLoader(num_workers=0, pin_memory=False), or ds.batch(indices)), not from "
+                "DataLoader worker processes")
         out = self._run([self._plan(i)])
         return tuple(o[0] if torch.is_tensor(o) else o for o in out)
 

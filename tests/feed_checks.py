@@ -89,3 +89,68 @@ def check_misc():
     for L, ps, e, c in m["calc_extended_patch_size"]:
         e2, c2 = calc_extended_patch_size(np.zeros(L), tuple(ps))
         assert list(e2) == e and [[s.start, s.stop] for s in c2] == c
+
+
+def check_loader(device):
+    """the three data sets through `torch.utils.data.DataLoader(num_workers=0, pin_memory=False)` with the
+    default collate (how a reference-style loop consumes them, train_all.py:294-301,502-509 minus the workers):
+    batched shapes and values against the fixtures of the same draws."""
+    from torch.utils.data import DataLoader
+    from rehrseg_amd.utils.train_set import TrainSetMultiple, TrainSetMultipleSegSR, TrainSetMultipleSegSREfficient
+    # stage 1
+    name = "multi_2d_blur"
+    shapes, ps, sep, blur, flip, seed, draws = MULTI_CASES[name]
+    g = np.load(os.path.join(GOLD, f"feed_{name}.npz"))
+    vols = volumes_multi(seed, shapes)
+    ds = TrainSetMultiple(None, list(range(len(vols))), sep, 1.0, None, None, ps, flip, device, blur=blur, volumes=vols,
+                          blur_kernel=KERNEL)
+    random.seed(seed)
+    (lr, hr), = list(DataLoader(ds, batch_size=len(vols), shuffle=False, num_workers=0, pin_memory=False))
+    assert lr.device.type == torch.device(device).type
+    assert tuple(lr.shape) == (len(vols),) + g["lr0"].shape and tuple(hr.shape) == (len(vols),) + g["hr0"].shape
+    for k in range(len(vols)):
+        np.testing.assert_array_equal(_np(hr[k]), g[f"hr{k}"])
+        np.testing.assert_allclose(_np(lr[k]), g[f"lr{k}"], rtol=1e-6, atol=1e-6)
+    # stage 2, efficient set (image, LR label, HR label, uncertainty)
+    name = "eff_unc"
+    shapes, ps, sep, unc, flip, norm, seed, draws = EFF_CASES[name]
+    g = np.load(os.path.join(GOLD, f"feed_{name}.npz"))
+    vols = volumes_seg(seed, shapes)
+    ds = TrainSetMultipleSegSREfficient(None, list(range(len(vols))), float(sep), 1.0, ps, None, flip, unc, norm=norm,
+                                        device=device, volumes=vols)
+    random.seed(seed)
+    (img, lab_lr, lab, u), = list(DataLoader(ds, batch_size=len(vols), shuffle=False, num_workers=0, pin_memory=False))
+    assert tuple(img.shape) == (len(vols),) + g["img0"].shape and tuple(lab.shape) == (len(vols),) + g["lab0"].shape
+    for k in range(len(vols)):
+        np.testing.assert_allclose(_np(img[k]), g[f"img{k}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(_np(lab_lr[k]), g[f"lab_lr{k}"])
+        np.testing.assert_array_equal(_np(lab[k]), g[f"lab{k}"])
+        np.testing.assert_allclose(_np(u[k]), g[f"unc{k}"], rtol=1e-6, atol=1e-6)
+    # stage 2, plain set: items of one subject at a time (the subjects' patch shapes differ)
+    name = "segsr"
+    shapes, ps, flip, seed, draws = SEGSR_CASES[name]
+    g = np.load(os.path.join(GOLD, f"feed_{name}.npz"))
+    vols = volumes_multi(seed, shapes)
+    ds = TrainSetMultipleSegSR(None, list(range(len(vols))), 4.0, 1.0, ps, flip, device=device, volumes=vols)
+    random.seed(seed)
+    for k, (img, lab) in enumerate(DataLoader(ds, batch_size=1, shuffle=False, num_workers=0, pin_memory=False)):
+        np.testing.assert_array_equal(_np(img[0]), g[f"img{k}"])
+        np.testing.assert_array_equal(_np(lab[0]), g[f"lab{k}"])
+    assert k == len(vols) - 1
+
+
+def check_worker_guard(device, monkeypatch):
+    """A DataLoader worker process must get a clear error instead of touching the GPU runtime it inherited."""
+    import torch.utils.data
+    from rehrseg_amd import lib
+    from rehrseg_amd.utils.train_set import TrainSetMultipleSegSR
+    shapes, ps, flip, seed, draws = SEGSR_CASES["segsr"]
+    vols = volumes_multi(seed, shapes)
+    ds = TrainSetMultipleSegSR(None, list(range(len(vols))), 4.0, 1.0, ps, flip, device=device, volumes=vols)
+    monkeypatch.setattr(torch.utils.data, "get_worker_info", lambda: object())
+    try:
+        ds[0]
+    except lib.RehrsegHipError as e:
+        assert "num_workers=0" in str(e)
+    else:
+        raise AssertionError("a worker-side __getitem__ must raise")

@@ -66,3 +66,21 @@ def test_reference_data_imports_resolve():
     out = subprocess.run([sys.executable, "-c", code % os.path.join(root, "rehrseg_amd")], capture_output=True, text=True,
                          cwd="/tmp", env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_aliased_modules_keep_their_real_spec():
+    """the alias loader must not leave `__spec__` pointing at the alias name -- lazy relative imports
+    inside the mirrored modules would warn (`__package__ != __spec__.parent`), fatally under -W error."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import utils.seg_utils as su, models.seg_model as sm, models.FLAVR.FLAVR_arch as fa\n"
+            "import rehrseg_amd.utils.seg_utils as real\n"
+            "assert su is real\n"
+            "for m, n in ((su, 'rehrseg_amd.utils.seg_utils'), (sm, 'rehrseg_amd.models.seg_model'),\n"
+            "             (fa, 'rehrseg_amd.models.FLAVR.FLAVR_arch')):\n"
+            "    assert m.__spec__.name == n and m.__spec__.parent == m.__package__, (m.__spec__, m.__package__)\n"
+            "exec('from .. import lib as _l', su.__dict__)    # a lazy relative import, as _FusedBCEDice.forward does\n"
+            "print('SPEC_OK')\n" % os.path.join(ROOT, "rehrseg_amd"))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-W", "error::ImportWarning", "-c", code], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "SPEC_OK" in r.stdout, r.stderr[-2000:]

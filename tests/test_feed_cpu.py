@@ -113,3 +113,11 @@ def test_view_algebra_matches_numpy():
         got = emu_patch_gather([item], dims)[0].numpy().reshape(v.shape)
         np.testing.assert_array_equal(got, a, err_msg=f"trial {trial}")
 
+
+
+def test_through_a_dataloader(emulated):
+    feed_checks.check_loader("cpu")
+
+
+def test_worker_processes_are_refused(emulated, monkeypatch):
+    feed_checks.check_worker_guard("cpu", monkeypatch)

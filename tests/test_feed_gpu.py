@@ -126,3 +126,8 @@ def test_training_size_properties():
     dims = [3 - k for k in range(3) if fl[k]]  # (x, y, z) -> axes of (1, z, y, x)
     np.testing.assert_array_equal(torch.flip(lab_f, dims).cpu().numpy() if dims else lab_f.cpu().numpy(),
                                   lab.cpu().numpy())
+
+
+def test_through_a_dataloader():
+    """num_workers=0 / pin_memory=False: the only loader configuration device-resident data sets admit."""
+    feed_checks.check_loader(DEV)

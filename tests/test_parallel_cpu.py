@@ -221,3 +221,67 @@ def test_train_sr_step_with_raw_optimizer_keeps_ranks_in_lockstep():
     for n in pa:
         assert (pa[n] == pb[n]).all(), n                      # ... identical parameters after two steps
     assert la[1] != la[0]
+
+
+def test_direct_route_survives_zero_grad_after_forward():
+    """the reference's loops clear gradients AFTER the forward (train_all.py:135-137); the use counts
+    of that forward must survive PatchParallel.zero_grad(), or the weight-gradient kernels never write in place.
+    Single process, ABI emulation; gradients equal those of the run without PatchParallel."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_backend
+    from oracle.detinit import det_input, det_tensor
+    from rehrseg_amd import ops
+    from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+    from rehrseg_amd.parallel import PatchParallel
+    from rehrseg_amd.train_steps import train_sr_step
+    from rehrseg_amd.utils.seg_utils import BCEDiceLoss
+    prev = ops.get_backend() if hasattr(ops, "get_backend") else None
+    ops.set_backend(emu_backend)
+    try:
+        lr_p = det_input("pp.lr", (1, 2, 4, 16, 16), "rand")
+        hr_p = det_input("pp.hr", (1, 2, 16, 16, 16), "rand")
+        hr_p[:, 1:] = (hr_p[:, 1:] > 0.5).float()
+
+        class _NoStep:                                           # keeps the parameters, so both runs see the same weights
+            def zero_grad(self, set_to_none=True):
+                for p in self.ps:
+                    p.grad = None
+
+            def step(self):
+                pass
+
+        def run(with_pp):
+            m = UNet_3D_3D(2, "unet_18", 4, 4)
+            m.load_state_dict({k: det_tensor(k, tuple(v.shape)) for k, v in m.state_dict().items()})
+            opt = _NoStep()
+            opt.ps = list(m.parameters())
+            seen = {}
+            if with_pp:
+                direct = [p for p in m.parameters() if p.dim() == 5]
+                pp = PatchParallel(m, direct=direct)
+
+                def sync():
+                    seen["written"] = sum(pp.was_written(p) for p in direct)
+                    seen["direct"] = sum(1 for n, p in m.named_parameters()
+                                         if p.dim() == 5 and "attn_layer" not in n and "stem" not in n)
+                    pp.reduce_gradients()
+                for _ in range(2):                               # the second step must behave like the first
+                    train_sr_step(m, opt, None, lr_p.clone(), hr_p, torch.nn.L1Loss(), BCEDiceLoss(1.0, 1.0), 4.0, 4,
+                                  False, grad_sync=sync, zero_grad=pp.zero_grad)
+                pp.close()
+            else:
+                train_sr_step(m, opt, None, lr_p.clone(), hr_p, torch.nn.L1Loss(), BCEDiceLoss(1.0, 1.0), 4.0, 4, False)
+            return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}, seen
+
+        g_pp, seen = run(True)
+        g_ref, _ = run(False)
+        # every conv weight that goes through conv_wgrad's generic path takes the in-place route (the SEGating
+        # 1x1x1 weights get their gradient from se_gate_bwd, the stem is a thin-input layer)
+        assert seen["written"] == seen["direct"] == 24, seen
+        assert set(g_pp) == set(g_ref) and len(g_ref) > 60
+        for n in g_ref:
+            assert torch.allclose(g_pp[n], g_ref[n], atol=1e-6, rtol=1e-5), n
+    finally:
+        if prev is not None:
+            ops.set_backend(prev)
