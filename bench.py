@@ -3,15 +3,25 @@
 1x1x128x128x128 fp32 patch per GPU (BASELINE.json configs[1]).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1, started plainly: this process never touches a GPU; it starts N ranks itself
+  (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>),
+  lets rank 0's JSON line through and exits with the launcher's code.  Started BY torch.distributed.run
+  (RANK / WORLD_SIZE in the environment) it is one of those ranks.
 
 A step = x.clone -> forward -> L1 loss -> backward -> (N>1: RCCL gradient all-reduce)
 -> Adam update.  Inputs are synthetic and resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.
+
+Order inside a rank: build -> W warm-up steps -> barrier + synchronize -> K timed steps (nothing but the step and one
+HIP event per step boundary on the launch stream) -> synchronize + barrier -> [rank 0, N=1: CPU oracle leg] ->
+a separate, untimed pass with HIP events around every matrix-core launch (the roofline families).  `value` is
+patches / wall-clock of the K timed steps (max over ranks); `step_ms` gives median / min / max of the K steps.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -77,7 +87,7 @@ def cpu_baseline(size, state_dict, x, tgt, timed=3):
         loss.backward()
         dt = time.perf_counter() - t0
         if it == 0:
-            first = (out.detach(), float(loss))
+            first = (out.detach(), float(loss.detach()))
         else:
             times.append(dt)
         del sd, out, loss
@@ -91,6 +101,21 @@ def cpu_baseline(size, state_dict, x, tgt, timed=3):
     return rec, first
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started plainly: start the N ranks as ONE child job of torch.distributed.run with
+    the flags this process got, from a parent that has made no GPU call (importing torch makes none).  Rank 0's JSON
+    line goes to the inherited stdout; returns the launcher's exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +125,7 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
                     help="bf16 = ops.mixed_precision(): bf16 operands on the matrix cores, fp32 accumulate / statistics / "
                          "master weights (BASELINE.json configs[4]); default fp32 (bf16 for --workload cfg5)")
-    ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref", "cfg4", "cfg5"], default="flavr",
+    ap.add_argument("--workload", choices=["flavr", "seg", "flavr_ref", "cfg4", "cfg5", "stub"], default="flavr",
                     help="flavr = configs[1] (headline); seg = configs[2] (SegModel 2x1x128^3, secondary); "
                          "flavr_ref = the reference's own stage-1 training shape, UNet_3D_3D(2,..,4,4) on "
                          "(B,2,4,96,96) with the UASR head (configs/brain.yaml)")
@@ -108,19 +133,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps of the cpu_baseline leg (after 1 warm-up)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-steps", type=int, default=0,
+                    help="steps of the separate per-kernel timing pass (0: max(--steps, 50), at most 100)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + --workload stub: the launch / exchange / report plumbing on CPU ranks (tests)")
     args = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # one rank of a torch.distributed.run job
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args.gpus))                            # before anything touches a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "TORCHELASTIC_RUN_ID" in os.environ  # started by torch.distributed.run (also with one rank)
-    if args.gpus > 1 or world > 1 or launched:
+    if launched and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    on_cpu = args.backend == "gloo"
+    if on_cpu and args.workload != "stub":
+        raise SystemExit("--backend gloo runs the stub workload only: the product path has no CPU fallback")
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if not on_cpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if on_cpu:
+        dev = torch.device("cpu")
+    else:
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
 
     from rehrseg_amd import hip_backend
     from rehrseg_amd.parallel import PatchParallel
@@ -137,7 +177,27 @@ def main():
     from rehrseg_amd import ops
     size = args.size
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # every rank draws its own patch
-    if args.workload == "flavr":
+    if args.workload == "stub":
+        # plumbing only (tests): a two-layer torch Conv3d net, no HIP kernels; exercises the launch, the flat-bucket
+        # exchange and the report with CPU ranks
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.ReLU(),
+                                    torch.nn.Conv3d(4, 1, 3, padding=1)).to(dev)
+        pp = PatchParallel(model, bucket_mb=1e-4, direct=[])
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        x = torch.rand(1, 1, 8, 8, 8, generator=g).to(dev)
+        tgt = torch.rand(1, 1, 8, 8, 8, generator=g).to(dev)
+        patches_per_step = 1
+        workload = "stub: 2-layer torch Conv3d net on 1x1x8^3 (launch / exchange / report plumbing, not a measurement)"
+
+        def step():
+            pp.zero_grad()
+            loss = (model(x) - tgt).abs().mean()
+            loss.backward()
+            pp.reduce_gradients()
+            opt.step()
+            return loss
+    elif args.workload == "flavr":
         model = build_model(size, dev)
         pp = PatchParallel(model)
         opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
@@ -244,38 +304,66 @@ def main():
             with ops.mixed_precision():
                 return plain_step()
         workload = "[bf16 mixed precision: bf16 MFMA operands, fp32 accumulate / statistics / master weights] " + workload
-    # CPU leg FIRST (rank 0, N=1, headline workload): the oracle on the host cores with the GPU model's own initial
-    # weights and patch; its warm-up step doubles as the parity check of the HIP forward (north_star: within 1e-3).
-    cpu_rec = parity = None
-    if world == 1 and not args.no_cpu_baseline and args.workload == "flavr" and not mixed:
+    def sync():
+        if not on_cpu:
+            torch.cuda.synchronize()
+
+    # parity inputs of the CPU leg: the model's INITIAL weights and its forward on the bench patch, taken before
+    # the first step (the CPU leg itself runs after the timed region)
+    cpu_leg = world == 1 and not args.no_cpu_baseline and args.workload == "flavr" and not mixed
+    if cpu_leg:
         sd0 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cpu_rec, (ref_out, ref_loss) = cpu_baseline(size, sd0, x.cpu(), tgt.cpu(), args.cpu_steps)
         with torch.no_grad():
             out0 = model(x.clone())
             loss0 = float((out0 - tgt).abs().mean())
-        parity = {"fwd_rel": float((out0.cpu() - ref_out).abs().max() / ref_out.abs().max()),
-                  "loss_rel": abs(loss0 - ref_loss) / abs(ref_loss), "loss_hip": loss0, "loss_cpu": ref_loss,
-                  "what": "HIP forward vs the CPU oracle's forward on identical weights / input, before the first step"}
-        del sd0, ref_out, out0
+        out0 = out0.cpu()
     for _ in range(args.warmup):
         step()
     if dist.is_initialized():
         dist.barrier()
-    torch.cuda.synchronize()
-    if not args.no_kernel_timing:
-        hip_backend.profile_start()
+    sync()
+    # ---- the timed region: exactly K steps; per-step boundaries are HIP events on the launch stream
+    marks = None if on_cpu else [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if marks:
+        marks[0].record()
+    for i in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
+        if marks:
+            marks[i + 1].record()
+    sync()
     if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = hip_backend.profile_stop() if not args.no_kernel_timing else {}
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if marks else []
+    final_loss = float(loss.item())
+
+    # ---- CPU leg (rank 0, N=1, headline workload): the oracle on the host cores with the GPU model's own initial
+    # weights and patch; its warm-up step doubles as the parity check of the HIP forward (north_star: within 1e-3)
+    cpu_rec = parity = None
+    if cpu_leg:
+        cpu_rec, (ref_out, ref_loss) = cpu_baseline(size, sd0, x.cpu(), tgt.cpu(), args.cpu_steps)
+        parity = {"fwd_rel": float((out0 - ref_out).abs().max() / ref_out.abs().max()),
+                  "loss_rel": abs(loss0 - ref_loss) / abs(ref_loss), "loss_hip": loss0, "loss_cpu": ref_loss,
+                  "what": "HIP forward vs the CPU oracle's forward on identical weights / input, before the first step"}
+        del sd0, ref_out, out0
+
+    # ---- per-kernel pass, untimed: HIP events around every matrix-core launch.  Separate from the timed region
+    # (the events cost host time per launch) and LAST in the process, after the CPU leg.
+    prof, ksteps = {}, 0
+    if not args.no_kernel_timing and not on_cpu:
+        ksteps = args.kernel_steps or min(100, max(args.steps, 50))
+        for _ in range(2):
+            step()                                  # the GPU idled through the CPU leg
+        torch.cuda.synchronize()
+        hip_backend.profile_start()
+        for _ in range(ksteps):
+            step()
+        prof = hip_backend.profile_stop()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -287,8 +375,12 @@ def main():
             "config": {"workload": workload, "patches_per_gpu": patches_per_step,
                        "global_batch": world * patches_per_step,
                        "parallelism": f"dp{world} (patch-parallel, flat-bucket RCCL all-reduce)"},
-            "loss": float(loss.item()),
+            "loss": final_loss,
         }
+        if step_ms:
+            rec["step_ms"] = {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1],
+                              "what": "HIP-event time of each of the K timed steps on the launch stream"}
+            rec["value_at_median_step"] = world * patches_per_step / (rec["step_ms"]["median"] * 1e-3)
         EXEC = {"wino_conv": 16.0 / 36.0, "wino_wgrad": 16.0 / 36.0,      # F(2x2,3x3): 16 of 36 products issued
                 "wino22_conv": 9.0 / 16.0, "wino22_wgrad": 9.0 / 16.0,    # F(2x2,2x2): 9 of 16
                 "gather_gemm": 1.0, "wgrad": 1.0, "gather_gemm_bf16": 1.0, "wgrad_bf16": 1.0}
@@ -308,12 +400,12 @@ def main():
                     "frac": ex / peak, "traffic": None,
                     "algorithmic_achieved": alg, "algorithmic_frac": alg / peak,
                     "mfma_products_issued_per_algorithmic": EXEC[name],
-                    "launches_per_step": f["launches"] / args.steps,
+                    "launches_per_step": f["launches"] / ksteps,
                     "avg_launch_ms": f["seconds"] / f["launches"] * 1e3,
-                    "ms_per_step": f["seconds"] / args.steps * 1e3,
-                    "algorithmic_gflop_per_step": f["flops"] / args.steps / 1e9}
+                    "ms_per_step": f["seconds"] / ksteps * 1e3,
+                    "algorithmic_gflop_per_step": f["flops"] / ksteps / 1e9}
 
-        names = {"wino_conv": "wino_conv_big8_kernel / wino_conv_w32_kernel / wino_conv_kernel / wino_flat_conv_kernel: "
+        names = {"wino_conv": "wino_conv_big8_kernel / wino_conv_w32p_kernel / wino_flat8_conv_kernel / wino_conv_kernel: "
                               "Winograd F(2x2,3x3)-over-(H,W) fp32 MFMA conv forward / input gradient",
                  "gather_gemm": "gather_gemm_kernel / halo_conv_kernel: fp32 MFMA implicit-GEMM conv (strided, 1x1x1, "
                                 "transposed phases)",
@@ -340,7 +432,9 @@ def main():
             if r and n != dominant:
                 rec["roofline_" + n] = r
         if prof:
-            rec["mfma_kernel_ms_per_step"] = sum(v["seconds"] for v in prof.values()) / args.steps * 1e3
+            rec["mfma_kernel_ms_per_step"] = sum(v["seconds"] for v in prof.values()) / ksteps * 1e3
+            rec["kernel_timing"] = (f"HIP events around every matrix-core launch over {ksteps} further steps after the "
+                                    "timed region (not inside it)")
         if cpu_rec is not None:
             rec["cpu_baseline"] = cpu_rec
             rec["parity_vs_cpu"] = parity

@@ -4,7 +4,7 @@ import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flag, workload, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
 for val in ("True", "False", "True", "False"):
-    argv = ["bench.py", "--workload", workload, "--steps", "30", "--no-cpu-baseline"] + extra
+    argv = ["bench.py", "--workload", workload, "--steps", "30", "--no-cpu-baseline", "--no-kernel-timing"] + extra
     code = ("import sys; sys.path.insert(0, %r); sys.argv=%r;"
             "from rehrseg_amd import hip_backend as hb; hb.%s = %s; import runpy; runpy.run_path(%r, run_name='__main__')"
             % (root, argv, flag, val, os.path.join(root, "bench.py")))
