@@ -18,8 +18,12 @@ import torch.nn.functional as F
 from . import flavr_oracle as fo
 
 
-def distiller_loss(w, b, fs, ft, lambda_l1, lambda_cosine, lambda_structure):
+def distiller_loss(w, b, fs, ft, lambda_l1, lambda_cosine, lambda_structure, emu=None):
+    """emu (oracle/bf16_emul.py): the 1x1x1 projection takes bf16 operands and stores bf16 on the mixed-precision path;
+    the structure / cosine statistics are fp32 there (on the bf16 feature values)."""
     loss = 0
+    if emu is not None:
+        fs = emu.act(fs)
     if lambda_structure > 0:
         Bn, C, S, Hh, Ww = fs.shape
         to2d = lambda t: t.permute(0, 2, 1, 3, 4).reshape(Bn * S, C, Hh, Ww)
@@ -33,7 +37,7 @@ def distiller_loss(w, b, fs, ft, lambda_l1, lambda_cosine, lambda_structure):
         ps, pt = pool(fs), pool(ft)
         err = (gram(pt) - gram(ps)).pow(2) / ((pt.shape[-1] * pt.shape[-2]) ** 2) / pt.shape[0]
         loss = loss + lambda_structure * err.sum() / S
-    d = F.conv3d(fs, w, b)
+    d = F.conv3d(fs, w, b) if emu is None else emu.act(F.conv3d(fs, emu.weight(w), b))
     if lambda_l1 > 0:
         loss = loss + lambda_l1 * F.smooth_l1_loss(d, ft)
     if lambda_cosine > 0:
@@ -85,7 +89,10 @@ def zscore(image):
     return torch.stack(outs, 0)
 
 
-def teacher_features(sd, img_lr, label_lr, img_channels=2, n_inputs=4, n_outputs=4, use_uncertainty=True):
+def teacher_features(sd, img_lr, label_lr, img_channels=2, n_inputs=4, n_outputs=4, use_uncertainty=True, emu=None,
+                     upto=4):
+    """upto < 4 stops every window's encoder after that level (the levels up to it are unchanged: the encoder is a
+    chain) -- the full-size tests only need level 1 and the CPU time of 127 windows matters there."""
     img_lr = zscore(img_lr)
     x = torch.cat((img_lr, label_lr), 1)
     D = x.shape[2]
@@ -100,7 +107,7 @@ def teacher_features(sd, img_lr, label_lr, img_channels=2, n_inputs=4, n_outputs
         else:
             w = x[:, :, st - 1:st + 3]
         last = fo.unet_3d_3d(sd, w.clone(), img_channels, n_inputs, n_outputs, use_uncertainty,
-                             return_intermediate_feature=True)
+                             return_intermediate_feature=True, emu=emu, upto=upto)
         for i, f in enumerate(last):
             per.setdefault(i, []).append(f[:, :, 1:2])
     for i, f in enumerate(last):

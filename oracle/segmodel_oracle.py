@@ -23,43 +23,76 @@ def _t(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * 3
 
 
-def _cna(sd, p, x, k, stride, eps, slope):
+def _cna(sd, p, x, k, stride, eps, slope, emu=None):
     k = _t(k)
-    y = F.conv3d(x, sd[p + "conv.weight"], sd.get(p + "conv.bias"), _t(stride), tuple((i - 1) // 2 for i in k))
-    y = F.instance_norm(y, weight=sd[p + "norm.weight"], bias=sd[p + "norm.bias"], eps=eps)
-    return F.leaky_relu(y, slope)
+    pad = tuple((i - 1) // 2 for i in k)
+    if emu is None or x.shape[1] <= 2:                                       # (thin-input layers stay fp32 on the device)
+        y = F.conv3d(x, sd[p + "conv.weight"], sd.get(p + "conv.bias"), _t(stride), pad)
+        y = F.instance_norm(y, weight=sd[p + "norm.weight"], bias=sd[p + "norm.bias"], eps=eps)
+        return F.leaky_relu(y, slope)
+    # mixed precision (oracle/bf16_emul.py): bf16 operands, statistics from the unrounded accumulators, the conv output
+    # and the block output stored as bf16
+    y = F.conv3d(emu.act(x), emu.weight(sd[p + "conv.weight"]), sd.get(p + "conv.bias"), _t(stride), pad)
+    mean = y.mean(dim=(2, 3, 4), keepdim=True)
+    var = y.var(dim=(2, 3, 4), unbiased=False, keepdim=True)
+    g, b = sd[p + "norm.weight"].view(1, -1, 1, 1, 1), sd[p + "norm.bias"].view(1, -1, 1, 1, 1)
+    return emu.act(F.leaky_relu((emu.act(y) - mean) * torch.rsqrt(var + eps) * g + b, slope))
 
 
-def seg_model(sd, x, cfg, return_features=False):
+def _sr_head0_emu(sd, feats, upscale, emu):
+    """sr_head.0 as the device computes it in mixed precision: the in-plane 3x3 part of each depth tap on the
+    LOW-resolution features (48 bf16 response channels), then depth interpolation + depth-tap sum + bias + ReLU."""
+    w, b = emu.weight(sd["sr_head.0.weight"]), sd["sr_head.0.bias"]
+    x = emu.act(feats)
+    tot = 0
+    for kd in range(3):
+        r = emu.act(F.conv3d(x, w[:, :, kd:kd + 1], None, 1, (0, 1, 1)))
+        u = F.interpolate(r, scale_factor=(upscale, 1, 1), mode="trilinear", align_corners=True)
+        u = F.pad(u, (0, 0, 0, 0, 1, 1))                                     # the 3-tap depth conv's zero padding
+        tot = tot + u[:, :, kd:kd + u.shape[2] - 2]
+    return emu.act(torch.relu(tot + b.view(1, -1, 1, 1, 1)))
+
+
+def seg_model(sd, x, cfg, return_features=False, emu=None):
     """cfg: dict(n_stages, features_per_stage, kernel_sizes, strides, n_conv_per_stage,
-    n_conv_per_stage_decoder, num_classes, upscale, eps, slope, deep_supervision)."""
+    n_conv_per_stage_decoder, num_classes, upscale, eps, slope, deep_supervision).
+    emu: oracle/bf16_emul.Bf16Emu() rounds where the mixed-precision device path stores bf16 (None: plain)."""
     eps, slope = cfg.get("eps", 1e-5), cfg.get("slope", 0.01)
     n = cfg["n_stages"]
     skips = []
     for s in range(n):
         for i in range(cfg["n_conv_per_stage"][s]):
             x = _cna(sd, f"encoder.stages.{s}.0.convs.{i}.", x, cfg["kernel_sizes"][s],
-                     cfg["strides"][s] if i == 0 else 1, eps, slope)
+                     cfg["strides"][s] if i == 0 else 1, eps, slope, emu)
         skips.append(x)
     lres, segs, feats = skips[-1], [], None
     for s in range(n - 1):
         st = _t(cfg["strides"][-(s + 1)])
-        up = F.conv_transpose3d(lres, sd[f"decoder.transpconvs.{s}.weight"], sd.get(f"decoder.transpconvs.{s}.bias"), st)
+        if emu is None:
+            up = F.conv_transpose3d(lres, sd[f"decoder.transpconvs.{s}.weight"], sd.get(f"decoder.transpconvs.{s}.bias"), st)
+        else:
+            up = emu.act(F.conv_transpose3d(emu.act(lres), emu.weight(sd[f"decoder.transpconvs.{s}.weight"]),
+                                            sd.get(f"decoder.transpconvs.{s}.bias"), st))
         x = torch.cat((up, skips[-(s + 2)]), 1)
         for i in range(cfg["n_conv_per_stage_decoder"][s]):
-            x = _cna(sd, f"decoder.stages.{s}.convs.{i}.", x, cfg["kernel_sizes"][-(s + 2)], 1, eps, slope)
+            x = _cna(sd, f"decoder.stages.{s}.convs.{i}.", x, cfg["kernel_sizes"][-(s + 2)], 1, eps, slope, emu)
         if s == n - 2:
             feats = x
+        xs = x if emu is None else emu.act(x)   # the fp32 logits layer reads the bf16 features; its input gradient is cast back
         if cfg.get("deep_supervision", False):
-            segs.append(F.conv3d(x, sd[f"decoder.seg_layers.{s}.weight"], sd[f"decoder.seg_layers.{s}.bias"]))
+            segs.append(F.conv3d(xs, sd[f"decoder.seg_layers.{s}.weight"], sd[f"decoder.seg_layers.{s}.bias"]))
         elif s == n - 2:
-            segs.append(F.conv3d(x, sd[f"decoder.seg_layers.{n - 2}.weight"], sd[f"decoder.seg_layers.{n - 2}.bias"]))
+            segs.append(F.conv3d(xs, sd[f"decoder.seg_layers.{n - 2}.weight"], sd[f"decoder.seg_layers.{n - 2}.bias"]))
         lres = x
     segs = segs[::-1]
     out = segs if cfg.get("deep_supervision", False) else segs[0]
-    up = F.interpolate(feats, scale_factor=(cfg["upscale"], 1, 1), mode="trilinear", align_corners=True)
-    up = torch.relu(F.conv3d(up, sd["sr_head.0.weight"], sd["sr_head.0.bias"], 1, 1))
-    up = F.conv3d(up, sd["sr_head.2.weight"], sd["sr_head.2.bias"], 1, 2)
+    if emu is None:
+        up = F.interpolate(feats, scale_factor=(cfg["upscale"], 1, 1), mode="trilinear", align_corners=True)
+        up = torch.relu(F.conv3d(up, sd["sr_head.0.weight"], sd["sr_head.0.bias"], 1, 1))
+        up = F.conv3d(up, sd["sr_head.2.weight"], sd["sr_head.2.bias"], 1, 2)
+    else:
+        up = _sr_head0_emu(sd, feats, cfg["upscale"], emu)
+        up = F.conv3d(up, emu.weight(sd["sr_head.2.weight"]), sd["sr_head.2.bias"], 1, 2)   # bf16 operands, fp32 logits
     if return_features:
         return out, up, skips
     return out, up

@@ -32,8 +32,16 @@ def test_distiller_oracle_and_product():
     m = Distiller(64, 64, 0.0, 1.0, 1.0)
     m.load_state_dict({k: det_tensor(k, tuple(v.shape)) for k, v in m.state_dict().items()})
     fs2, _ = _dist_inputs()
-    l2 = m(fs2, ft)
-    l2.backward()
+    from rehrseg_amd import lib, ops
+    with pytest.raises(lib.RehrsegHipError):                     # the product has no CPU path of its own
+        m(fs2, ft)
+    import emu_backend
+    prev = ops.set_backend(emu_backend)                          # host wiring on the test-only ABI emulation
+    try:
+        l2 = m(fs2, ft)
+        l2.backward()
+    finally:
+        ops.set_backend(prev)
     assert abs(l2.item() - float(G["dist_loss"])) < 1e-6
     assert close(fs2.grad.numpy(), G["dist_grad_fs"], 1e-4) and close(m.distill.bias.grad.numpy(), G["dist_grad_b"], 1e-4)
 
