@@ -18,6 +18,7 @@ a separate, untimed pass with HIP events around every matrix-core launch (the ro
 patches / wall-clock of the K timed steps (max over ranks); `step_ms` gives median / min / max of the K steps.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -321,6 +322,14 @@ def main():
     sync()
     # ---- the timed region: exactly K steps; per-step boundaries are HIP events on the launch stream
     marks = None if on_cpu else [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # Python's cyclic collector: a full (generation-2) pass walks every live object of the process and stalls the
+    # launching thread for tens of ms -- one 40 ms step per ~100.  The long-lived objects (model, optimizer, torch) are
+    # moved out of the collector's sight once, before the clock starts; young generations keep being collected.
+    gc.collect()
+    gc.freeze()
+    gc_log = []
+    gc_cb = lambda phase, info: gc_log.append((info["generation"], time.perf_counter())) if phase == "stop" else None
+    gc.callbacks.append(gc_cb)
     t0 = time.perf_counter()
     if marks:
         marks[0].record()
@@ -332,11 +341,13 @@ def main():
     if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.callbacks.remove(gc_cb)
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if marks else []
+    raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else []
+    step_ms = sorted(raw_ms)
     final_loss = float(loss.item())
 
     # ---- CPU leg (rank 0, N=1, headline workload): the oracle on the host cores with the GPU model's own initial
@@ -384,6 +395,8 @@ def main():
         }
         if step_ms:
             rec["step_ms"] = {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1],
+                              "slowest_step_index": raw_ms.index(step_ms[-1]),
+                              "gc_passes_in_timed_region": {str(g_): sum(1 for q in gc_log if q[0] == g_) for g_ in (0, 1, 2)},
                               "what": "HIP-event time of each of the K timed steps on the launch stream"}
             rec["value_at_median_step"] = world * patches_per_step / (rec["step_ms"]["median"] * 1e-3)
         EXEC = {"wino_conv": 16.0 / 36.0, "wino_wgrad": 16.0 / 36.0,      # F(2x2,3x3): 16 of 36 products issued
@@ -428,7 +441,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", "r02_pmc_hbm_flavr.json")
             if args.workload == "flavr" and size == 128 and dominant == "wino_conv" and os.path.exists(tp):
                 ks = json.load(open(tp)).get("kernels", {})
-                k = ks.get("wino_conv_big8_kernel") or ks.get("wino_conv_big_kernel") or {}
+                k = ks.get("wino_conv_big8_kernel") or {}
                 if k.get("hbm_bytes_per_launch"):
                     r["traffic"] = k["hbm_bytes_per_launch"]
                     r["traffic_source"] = "profiles/r02_pmc_hbm_flavr.json (PMC FETCH_SIZE x2 + WRITE_SIZE per launch)"

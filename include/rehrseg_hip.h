@@ -99,34 +99,24 @@ typedef struct {
    * (same fp32 results up to the transform's rounding, ~1e-6 relative).          */
   float* wino_ws;
   int64_t wino_ws_bytes;
-  int32_t flags;                   /* REHR_GG_* bits */
+  int32_t flags;                   /* REHR_GG_* bits; 0 = the library picks the measured-best kernel */
+  int32_t debug_flags;             /* REHR_DBG_GG_* bits (below): kernel-selection overrides for tests and A/B
+                                    * runs.  NOT part of the stable interface -- integrators leave it 0.        */
 } rehr_gather_gemm_desc;
 
 /* bf16 entry points: store y as fp32 instead of bf16 (logits, features handed to fp32 losses) */
 #define REHR_GG_Y_F32 1
-/* bf16 entry points: never take the LDS halo-brick kernel (tests compare it with the per-tap gather kernel) */
-#define REHR_GG_NO_HALO 2
 
-/* fp32 entry points: the eight-wave organisation of the big-tile Winograd kernel (two waves per SIMD) */
-#define REHR_GG_WINO_8WAVE 4
-/* bf16 entry points: the LDS halo-brick kernel with eight waves per block (two per SIMD) instead of four */
-#define REHR_GG_HALO_8WAVE 16
-/* fp32 entry points: the 32-channel-tile Winograd kernel with one 1024-thread block per CU instead of two 512-thread ones */
-#define REHR_GG_W32_ONE_PER_CU 8
-
-/* fp32 entry points: planes that 16 x 16-output regions tile badly (12 x 12, 24 x 24, ...) on the flattened-tile
- * kernel with the big-tile kernel's schedule (wino_flat8_conv.hip); _HALF / _FULL force 32 / 64 tiles per block
- * (default: whichever fills 256 CUs better) */
-#define REHR_GG_FLAT8 32
-#define REHR_GG_FLAT8_HALF 64
-#define REHR_GG_FLAT8_FULL 128
-
-/* fp32 entry points: the 32-channel-tile Winograd kernel (one block per CU) as 8 waves with the big-tile kernel's
- * software pipeline instead of 16 waves of thread-level parallelism */
-#define REHR_GG_W32_PIPELINED 256
-/* ... forced as two 256-thread blocks per CU (16 x 16 outputs each) / one 512-thread block (default: by K length) */
-#define REHR_GG_W32P_TWO_PER_CU 512
-#define REHR_GG_W32P_ONE_PER_CU 1024
+/* debug_flags (unstable; the parity tests compare kernel organisations with each other through them):
+ * bf16: never take the LDS halo-brick kernel (per-tap gather kernel instead) */
+#define REHR_DBG_GG_NO_HALO 1
+/* fp32: the flattened-tile Winograd kernels (wino_flat8_conv.hip, wino22_flat) off / forced to 32 or 64 tiles per block */
+#define REHR_DBG_GG_NO_FLAT8 2
+#define REHR_DBG_GG_FLAT8_HALF 4
+#define REHR_DBG_GG_FLAT8_FULL 8
+/* fp32: the 32-channel-tile Winograd kernel forced to two 256-thread blocks per CU / one 512-thread block */
+#define REHR_DBG_GG_W32P_TWO_PER_CU 16
+#define REHR_DBG_GG_W32P_ONE_PER_CU 32
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
@@ -193,22 +183,18 @@ typedef struct {
   float* workspace;                /* >= rehr_wgrad_workspace_bytes() */
   int64_t workspace_bytes;
   float* dbias;                    /* NULL or [Ca]: dbias[a] (+)= sum l[...,a] */
-  int32_t flags;                   /* REHR_WGRAD_* bits; 0 = let the library pick the kernel */
+  int32_t flags;                   /* reserved, 0 */
+  int32_t debug_flags;             /* REHR_DBG_WGRAD_* bits: kernel-selection overrides for tests and A/B runs;
+                                    * NOT part of the stable interface -- integrators leave it 0.  Everything that
+                                    * selects a kernel travels in the descriptors: the library reads no environment
+                                    * variables and keeps no mutable state between calls.                        */
 } rehr_wgrad_desc;
 
-/* flags: force the direct (slab / brick) kernels even where a transform-domain (Winograd) kernel applies.
- * Everything that selects a kernel travels in the descriptors: the library reads no environment
- * variables and keeps no mutable state between calls. */
-#define REHR_WGRAD_DIRECT 1
-/* Winograd weight gradient of layers with >= 64 channels on both sides: two 64 x 32 blocks per CU instead of one 64 x 64 */
-#define REHR_WGRAD_TWO_PER_CU 2
-/* the 64 x 64 block of the Winograd weight gradient as 8 waves (two per SIMD) instead of 4 */
-#define REHR_WGRAD_8WAVE 4
-/* bf16 weight gradient: the LDS brick kernel with eight waves per block (two per SIMD) instead of four */
-#define REHR_WGRAD_BRICK_8WAVE 8
+/* debug_flags: force the direct (slab / brick) kernels even where a transform-domain (Winograd) kernel applies */
+#define REHR_DBG_WGRAD_DIRECT 1
 /* Winograd weight gradient: walk every output slice for every depth tap (default: a tap skips the slices whose source
  * slice lies outside the volume; tests compare both) */
-#define REHR_WGRAD_NO_TAP_SKIP 16
+#define REHR_DBG_WGRAD_NO_TAP_SKIP 2
 
 /* Mixed-precision weight gradient: l and g point at bf16 elements (ld* in elements, % 8 == 0; Ca, Cg % 8 == 0),
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 slabs and fp32 dst (the master-weight gradient).  dbias must

@@ -485,7 +485,6 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
       int wrc = wino_flat8_conv_try(descs[i], st);
       if (wrc == REHR_ENOSUP) wrc = wino_conv_try(descs[i], st);
       if (wrc == REHR_ENOSUP) wrc = wino22_conv_try(descs[i], st);
-      if (wrc == REHR_ENOSUP) wrc = wino_flat_conv_try(descs[i], st);
       if (wrc == REHR_OK) continue;
       if (wrc != REHR_ENOSUP) return wrc;
     }
@@ -507,7 +506,6 @@ extern "C" int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* dp) 
   int64_t b = wino_flat8_workspace_bytes(*dp);
   if (b == 0) b = wino_workspace_bytes(*dp);
   if (b == 0) b = wino22_workspace_bytes(*dp);
-  if (b == 0) b = wino_flat_workspace_bytes(*dp);
   return b;
 }
 

@@ -533,25 +533,16 @@ int halo_conv_bf16_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     p.wp_bytes = (uint32_t)wb;
   }
   // brick shapes in order of preference; one that pads the lattice by more than 1.3x (or does not fit it) declines
+  // (eight waves per block, two per SIMD; the four-wave organisation of round 2's first half was 1.0 ms per step slower
+  // on the bf16 cfg-3 step: profiles/r03_ab_superseded.txt)
   int rc;
-  if (d.flags & REHR_GG_HALO_8WAVE) {
-    if (T == 27) {
-      rc = launch<4, 8, 16, 9, 8>(p, stream);
-      if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 9, 8>(p, stream);
-    } else {
-      rc = launch<4, 8, 16, 3, 8>(p, stream);
-      if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 3, 8>(p, stream);
-      if (rc == REHR_ENOSUP) rc = launch<2, 16, 16, 3, 8>(p, stream);
-    }
-    return rc;
-  }
   if (T == 27) {
-    rc = launch<4, 8, 16, 9, 4>(p, stream);
-    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 9, 4>(p, stream);
+    rc = launch<4, 8, 16, 9, 8>(p, stream);
+    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 9, 8>(p, stream);
   } else {
-    rc = launch<4, 8, 16, 3, 4>(p, stream);
-    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 3, 4>(p, stream);
-    if (rc == REHR_ENOSUP) rc = launch<2, 16, 16, 3, 4>(p, stream);
+    rc = launch<4, 8, 16, 3, 8>(p, stream);
+    if (rc == REHR_ENOSUP) rc = launch<8, 8, 8, 3, 8>(p, stream);
+    if (rc == REHR_ENOSUP) rc = launch<2, 16, 16, 3, 8>(p, stream);
   }
   return rc;
 }

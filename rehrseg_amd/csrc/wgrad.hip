@@ -640,7 +640,7 @@ extern "C" int64_t rehr_wgrad_bf16_workspace_bytes(const rehr_wgrad_desc* dp) {
   if (rc != REHR_OK) return rc;
   BrickBf16 bo;
   WGParams pb = p;
-  if (!(d.flags & REHR_WGRAD_DIRECT) && wgrad_brick_bf16_plan(d, pb, bo))
+  if (!(d.debug_flags & REHR_DBG_WGRAD_DIRECT) && wgrad_brick_bf16_plan(d, pb, bo))
     return (int64_t)pb.splits * pb.T * pb.Capad * pb.Cgpad * (int64_t)sizeof(float);
   return (int64_t)p.splits * p.T * p.Capad * p.Cgpad * (int64_t)sizeof(float);
 }
@@ -651,8 +651,8 @@ extern "C" int rehr_wgrad_bf16(const rehr_wgrad_desc* dp, void* stream) {
   int rc = plan_bf16(*dp, p);
   if (rc != REHR_OK) return rc;
   BrickBf16 bo;
-  // unit-stride 3x3(x3) taps: both operands as LDS bricks (REHR_WGRAD_DIRECT keeps the per-tap slab kernel)
-  const bool brick = !(dp->flags & REHR_WGRAD_DIRECT) && wgrad_brick_bf16_plan(*dp, p, bo);
+  // unit-stride 3x3(x3) taps: both operands as LDS bricks (REHR_DBG_WGRAD_DIRECT keeps the per-tap slab kernel)
+  const bool brick = !(dp->debug_flags & REHR_DBG_WGRAD_DIRECT) && wgrad_brick_bf16_plan(*dp, p, bo);
   const rehr_wgrad_desc& d = p.d;
   if (!d.workspace || d.workspace_bytes < (int64_t)p.splits * p.T * p.Capad * p.Cgpad * (int64_t)sizeof(float))
     return REHR_EINVAL;

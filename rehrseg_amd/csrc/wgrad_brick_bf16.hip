@@ -279,8 +279,8 @@ static int wgrad_brick_bf16_launch_t(const WGParams& w, const BrickBf16& o, hipS
 }
 
 int wgrad_brick_bf16_launch(const WGParams& w, const BrickBf16& o, hipStream_t stream) {
-  const bool w8 = (w.d.flags & REHR_WGRAD_BRICK_8WAVE) != 0;
-  if (w.d.td.count == 3)
-    return w8 ? wgrad_brick_bf16_launch_t<3, 8>(w, o, stream) : wgrad_brick_bf16_launch_t<3, 4>(w, o, stream);
-  return w8 ? wgrad_brick_bf16_launch_t<1, 8>(w, o, stream) : wgrad_brick_bf16_launch_t<1, 4>(w, o, stream);
+  // eight waves per block (<= 4 taps per wave); four waves measured 0.85 ms per bf16 cfg-3 step slower
+  // (profiles/r03_ab_superseded.txt)
+  if (w.d.td.count == 3) return wgrad_brick_bf16_launch_t<3, 8>(w, o, stream);
+  return wgrad_brick_bf16_launch_t<1, 8>(w, o, stream);
 }

@@ -611,7 +611,7 @@ int f22_conflicts(int ntw, int RPf) {
 }
 
 bool plan22_flat(const rehr_gather_gemm_desc& d, F22Params& p, int parts = 1) {
-  if (!(d.flags & REHR_GG_FLAT8) || d.sd != 1) return false;
+  if ((d.debug_flags & REHR_DBG_GG_NO_FLAT8) || d.sd != 1) return false;
   AxisPlan ah, aw;
   if (!plan_axis(d.th, d.sh, d.bh, ah) || !plan_axis(d.tw, d.sw, d.bw, aw)) return false;
   if (ah.nph != aw.nph) return false;

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(NTH) void wino22_wgrad_kernel(const WW22Params p) {
   const int ph_i = z / d.td.count, jd = z - ph_i * d.td.count;
   const Phase22& P = p.phase[ph_i];
   const int ca0 = at * 64, cg0 = ct * 64;
-  // a depth tap walks only the output slices whose source slice exists (unless REHR_WGRAD_NO_TAP_SKIP)
-  const bool skip = !(d.flags & REHR_WGRAD_NO_TAP_SKIP);
+  // a depth tap walks only the output slices whose source slice exists (unless REHR_DBG_WGRAD_NO_TAP_SKIP)
+  const bool skip = !(d.debug_flags & REHR_DBG_WGRAD_NO_TAP_SKIP);
   const int doff_ = d.bd + d.td.off0 + d.td.offs * jd;
   const int od_lo = skip ? max(0, -doff_) : 0, od_hi = skip ? min(d.Ld, d.Dg - doff_) : d.Ld;
   const int nod = max(0, od_hi - od_lo);
@@ -256,7 +256,7 @@ __global__ void wino22_wgrad_reduce_kernel(const WW22Params p) {
 }
 
 bool plan(const rehr_wgrad_desc& d, WW22Params& p) {
-  if ((d.flags & REHR_WGRAD_DIRECT) || d.dbias != nullptr) return false;
+  if ((d.debug_flags & REHR_DBG_WGRAD_DIRECT) || d.dbias != nullptr) return false;
   if (d.sd != 1) return false;
   AxisPlan ah, aw;
   if (!plan_axis(d.th, d.sh, d.bh, ah) || !plan_axis(d.tw, d.sw, d.bw, aw)) return false;

@@ -11,10 +11,9 @@ int64_t wino22_workspace_bytes(const rehr_gather_gemm_desc& d);
 int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
 // the output phases of one transposed convolution in one grid of the flattened-tile F(2x2,2x2) kernel
 int wino22_flat_multi_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t stream);
-// small-lattice variant with flattened tile numbering (wino_flat_conv.hip)
+// fragment-ordered weight transform shared by the big-tile, 32-channel-tile and flattened-tile kernels
 int wino_weights_frag_launch(const rehr_gather_gemm_desc& d, int kchunks, hipStream_t stream);
-int64_t wino_flat_workspace_bytes(const rehr_gather_gemm_desc& d);
-int wino_flat_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);
-// the same with the big-tile kernel's schedule and row-range staging (wino_flat8_conv.hip); tried first
+// small planes (12 x 12, 24 x 24, ...): flattened tile numbering, the big-tile kernel's schedule, row-range staging
+// (wino_flat8_conv.hip); tried first
 int64_t wino_flat8_workspace_bytes(const rehr_gather_gemm_desc& d);
 int wino_flat8_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream);

@@ -285,14 +285,14 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Big-tile variant: 64 Winograd tiles (16 x 16 outputs) x 64 channels per block, ONE block of
-// 4 waves per CU with the full register file (16 accumulator tiles per wave in AGPRs).  Each
-// weight fragment feeds 2 tile groups and each input fragment 2 channel groups, which halves
-// the L2->CU operand traffic per MFMA -- the limiter of the small-tile kernel above (measured:
-// 2.16 ms with, 1.45 ms without operand loads on 512->512 @ 128x16x16).  One wave per SIMD, so
-// all latency hiding is explicit: 4 k-group steps per item, the LDS reads / weight loads of
-// step k+1 in flight under the 64 MFMAs of step k; one barrier per item (256 MFMAs), placed
-// where nothing is pending.
+// Big-tile variant: 64 Winograd tiles (16 x 16 outputs) x 64 channels per block, ONE block per CU
+// with the full register file.  Each weight fragment feeds 2 tile groups and each input fragment 2
+// channel groups, which halves the L2->CU operand traffic per MFMA -- the limiter of the small-tile
+// kernel above (measured: 2.16 ms with, 1.45 ms without operand loads on 512->512 @ 128x16x16).
+// Latency hiding is explicit: the LDS reads / weight loads of the next k-group step in flight under
+// the MFMAs of the current one; one barrier per item, placed where nothing is pending.
+// (Rounds 1-2 ran this tile as 4 waves, one per SIMD with 16 accumulator tiles each; the 8-wave
+// organisation below replaced it: -1.5 ms per cfg-2 step, profiles/r03_ab_superseded.txt.)
 constexpr int PW2 = 18, PVOX2 = 18 * 18, NX2 = (PVOX2 * 8 + 255) / 256;  // 11 pieces per thread
 // LDS patch layout of the big-tile kernel: within a row the 9 even columns come first, then the 9 odd
 // ones, and rows are padded by 8 floats.  A fragment read touches, per 16-lane phase, tiles (th 0..1,
@@ -348,324 +348,9 @@ __global__ void wino_weights_frag_kernel(const rehr_gather_gemm_desc d, float* _
   }
 }
 
-__global__ __launch_bounds__(256) void wino_conv_big_kernel(const WinoParams p) {
-  const rehr_gather_gemm_desc& d = p.d;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;  // [2][BUF2]; reused as the row-combine exchange buffer at the end
-  constexpr int BUF = BUF2;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, col = lane & 31;
-  const int part = (p.nsplit > 1) ? (int)(blockIdx.z % p.nsplit) : 0;
-  const int n_img = (p.nsplit > 1) ? (int)(blockIdx.z / p.nsplit) : (int)blockIdx.z;
-  const rehr_axis_taps td = (p.nsplit > 1) ? p.s_td[part] : p.d.td;
-  const float* const up = (p.nsplit > 1) ? p.s_up[part] : p.up;
-  const uint32_t up_bytes = (p.nsplit > 1) ? p.s_up_bytes[part] : p.up_bytes;
-  float* const yout = (p.nsplit > 1) ? p.s_y[part] : p.d.y;
-  const int nt0 = blockIdx.y * 2, n0 = blockIdx.y * 64;
-  int b = xcd_remap(blockIdx.x, gridDim.x);
-  const int bw_ = b % p.nb_w; b /= p.nb_w;
-  const int bh_ = b % p.nb_h;
-  const int od = b / p.nb_h;
-  const int oh0 = bh_ * 16, ow0 = bw_ * 16;
-
-  const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
-  const float s2 = (r == 1) ? 1.f : -1.f;
-  const float rsign = (r == 2) ? -1.f : 1.f;
-  const int th_ = col >> 3, tw_ = col & 7;  // tile of group 0; group 1 = 4 tile rows further
-  const float* xa = Xs + (2 * th_ + i1) * RP2 + tw_ * LDX + 4 * half;  // column 2*tw_ + j -> slot (j&1)*9 + tw_ + (j>>1)
-  const float* xb = Xs + (2 * th_ + i2) * RP2 + tw_ * LDX + 4 * half;
-
-  // staging pieces of this thread (enumerated in LDS order): voxel index in the source slice, validity
-  int pvx[NX2];
-  uint32_t pok = 0;
-#pragma unroll
-  for (int i = 0; i < NX2; ++i) {
-    const int piece = tid + 256 * i;
-    const int v = piece >> 3;
-    const int ph = v / PW2, slot = v - ph * PW2;
-    const int pw_ = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
-    const int ih = oh0 + p.dh0 + ph, iw = ow0 + p.dw0 + pw_;
-    const bool ok = (piece < PVOX2 * 8) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
-    pvx[i] = ok ? ih * d.Wi + iw : 0;
-    pok |= (ok ? 1u : 0u) << i;
-  }
-  const int pq = tid & 7;  // 16-byte piece within the voxel's 32 channels (same for all i)
-  const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
-  constexpr int NXA = 6;  // pieces fetched / staged in the first half (the rest in the second)
-  f32x4 rx[NXA];
-  // depth taps whose source slice lies outside the volume contribute nothing for this whole block
-  // (od is block-uniform): walk only the valid range [jd_lo, jd_hi]
-  int jd_lo = td.count, jd_hi = -1;
-  for (int j = 0; j < td.count; ++j) {
-    const int id = od + d.bd + td.off0 + td.offs * j;
-    if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
-  }
-  const int items = p.kchunks * max(0, jd_hi - jd_lo + 1);
-  // items are walked with (chunk, depth tap) counters: no integer division inside the loop
-  struct Item { int chunk, jd; };
-  auto advance = [&](Item& t) {
-    if (++t.jd > jd_hi) { t.jd = jd_lo; ++t.chunk; }
-  };
-  auto fetch_to = [&](f32x4 (&rx)[NXA], const Item& t, const int lo, const int hi) {
-    const bool live = (t.chunk < p.kchunks) & (items > 0);
-    const int jd = t.jd;
-    const int cc = (live ? t.chunk : 0) * 32;
-    const int id = od + d.bd + td.off0 + td.offs * jd;
-    const bool first = cc < d.c1;
-    const float* src = first ? d.x1 : d.x2;
-    const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
-    const int coff = first ? cc : cc - d.c1;
-    const uint32_t nrec = img_elems * ld * 4u;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(src) + (int64_t)n_img * img_elems * ld, 0, nrec, 0x00020000);
-    const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
-    const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
-#pragma unroll
-    for (int i = lo; i < hi; ++i) {
-      const bool ok = dok & ((pok >> i) & 1u);
-      const uint32_t off = base + (uint32_t)pvx[i] * ld * 4u;
-      rx[i - lo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
-    }
-  };
-  auto stage_from = [&](const f32x4 (&rx)[NXA], int buf, const int lo, const int hi) {
-#pragma unroll
-    for (int i = lo; i < hi; ++i) {
-      const int piece = tid + 256 * i;
-      const int v = piece >> 3, row = (v * 3641) >> 16;  // v / 18 for v < 1024
-      if (piece < PVOX2 * 8) *reinterpret_cast<f32x4*>(Xs + buf + v * LDX + row * 8 + pq * 4) = rx[i - lo];
-    }
-  };
-  auto fetch = [&](const Item& t, const int lo, const int hi) { fetch_to(rx, t, lo, hi); };
-  auto stage = [&](int buf, const int lo, const int hi) { stage_from(rx, buf, lo, hi); };
-
-  const __amdgpu_buffer_rsrc_t rsu =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(up), 0, up_bytes, 0x00020000);
-  const int NT = d.Npad / 32;
-  const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
-  // the fragment address is wave-uniform except for the lane's 16 bytes: scalar offset operand, no VALU
-  const uint32_t ulane = (uint32_t)lane * 16u;
-  const uint32_t ubase = (uint32_t)(r * 4) * xi_stride + (uint32_t)nt0 * nt_stride;
-  auto load_u = [&](const Item& t, int kk, f32x4 (&ub)[2][4]) {
-    const int chunk = t.chunk < p.kchunks ? t.chunk : 0;  // (one item past the end is requested, never used)
-#ifdef WINO_DBG_SAMEW
-    const uint32_t base = ubase + 0u * (uint32_t)(t.jd + chunk + kk);
-#else
-    const uint32_t base = ubase + (uint32_t)(t.jd * 16) * xi_stride + (uint32_t)(chunk * 4 + kk) * 1024u;
-#endif
-#pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        ub[fn][c] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, base + c * xi_stride + fn * nt_stride, 0));
-  };
-
-  f32x16 acc[2][2][4];
-#pragma unroll
-  for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[fm][fn][c][q] = 0.f;
-
-  // A micro-step = (k-group kk, tile group fm) = 32 MFMAs.  While they run, the raw patch rows of
-  // the NEXT micro-step arrive from LDS and are combined (B^T d B, ~24 VALU slotted between the
-  // MFMAs) into its A fragments; weights arrive one k-group (2 micro-steps) ahead.
-  f32x4 ra[4], rb[4];
-  auto issue_reads = [&](int buf, const int kk, const int fm) {
-#ifdef WINO_DBG_NOLDS
-    return;
-#endif
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = *reinterpret_cast<const f32x4*>(xa + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LDX + kk * 8);
-      rb[j] = *reinterpret_cast<const f32x4*>(xb + buf + fm * FMOFF + ((j & 1) * 9 + (j >> 1)) * LDX + kk * 8);
-    }
-  };
-  // two floats per instruction (v_pk_fma_f32 / v_pk_add_f32): the A fragments live as float pairs
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  struct VFrag { f32x2 p[4][2]; };  // [column c][pair]: k-steps e = 2*pair + {0,1}
-  const f32x2 s2v = {s2, s2};
-  auto combine = [&](VFrag& v) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x2 R[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x2 a = h ? ra[j].hi : ra[j].lo, bq = h ? rb[j].hi : rb[j].lo;
-        R[j] = __builtin_elementwise_fma(bq, s2v, a);
-      }
-      v.p[0][h] = R[0] - R[2];
-      v.p[1][h] = R[1] + R[2];
-      v.p[2][h] = R[1] - R[2];  // negated column, undone at the output
-      v.p[3][h] = R[1] - R[3];
-    }
-  };
-  auto mfmas = [&](const int fm, const VFrag& v, const f32x4 (&ub)[2][4]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          acc[fm][fn][c] =
-              __builtin_amdgcn_mfma_f32_32x32x2f32(v.p[c][e >> 1][e & 1], ub[fn][c][e], acc[fm][fn][c], 0, 0, 0);
-  };
-// One scheduling region per micro-step: the loads of the next micro-step (ISSUE), the 32 MFMAs and
-// the combine's VALU are free to interleave, so the matrix pipe never waits for an issue phase (one
-// wave per SIMD: nobody else would fill the gap).  Explicit sched_group_barrier patterns (1 read per
-// MFMA, bursts, 2 MFMAs per memory instruction) all measured within 2 % of -- and slightly behind --
-// the compiler's own interleaving, so none is imposed.
-#define WINO_MICRO(fm, vcur, vnext, u, ISSUE)                            \
-  __builtin_amdgcn_sched_barrier(0);                                     \
-  ISSUE;                                                                 \
-  mfmas(fm, vcur, u);                                                    \
-  combine(vnext);                                                        \
-  __builtin_amdgcn_sched_barrier(0);
-
-  VFrag VA, VB;
-  f32x4 u0[2][4], u1[2][4];
-  Item ci = {0, min(jd_lo, td.count - 1)}, ni = ci;
-  {  // item 0: all 11 pieces in flight at once (u1's registers are free here)
-    fetch(ci, 0, NXA);
-    f32x4 (&rx2)[NXA] = reinterpret_cast<f32x4 (&)[NXA]>(u1);
-    fetch_to(rx2, ci, NXA, NX2);
-    load_u(ci, 0, u0);
-    stage(0, 0, NXA);
-    stage_from(rx2, 0, NXA, NX2);
-  }
-  __syncthreads();
-  issue_reads(0, 0, 0);
-  combine(VA);
-
-  for (int it = 0; it < items; ++it) {
-    const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
-    advance(ni);
-    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 0, 1), load_u(ci, 1, u1), fetch(ni, 0, NXA)))
-    WINO_MICRO(1, VB, VA, u0, issue_reads(cur, 1, 0))
-    WINO_MICRO(0, VA, VB, u1,
-               (issue_reads(cur, 1, 1), load_u(ci, 2, u0), stage(nxt, 0, NXA), fetch(ni, NXA, NX2)))
-    WINO_MICRO(1, VB, VA, u1, issue_reads(cur, 2, 0))
-    WINO_MICRO(0, VA, VB, u0, (issue_reads(cur, 2, 1), load_u(ci, 3, u1), stage(nxt, NXA, NX2)))
-    WINO_MICRO(1, VB, VA, u0, issue_reads(cur, 3, 0))
-    WINO_MICRO(0, VA, VB, u1, (issue_reads(cur, 3, 1), load_u(ni, 0, u0)))
-    // every read of slice `cur` has been consumed, every write of `nxt` was issued long ago
-#ifndef WINO_DBG_NOBAR
-    __syncthreads();
-#endif
-    WINO_MICRO(1, VB, VA, u1, issue_reads(nxt, 0, 0))
-    ci = ni;
-  }
-#undef WINO_MICRO
-  __syncthreads();
-
-  // ---- output transform: columns in registers, rows across the 4 waves through LDS
-  float* ex = smem;  // [fm*2+fn][r][c'][q][lane]
-#pragma unroll
-  for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-    for (int fn = 0; fn < 2; ++fn) {
-      const f32x16 T0 = (acc[fm][fn][0] + acc[fm][fn][1] - acc[fm][fn][2]) * rsign;
-      const f32x16 T1 = (acc[fm][fn][1] + acc[fm][fn][2] - acc[fm][fn][3]) * rsign;
-      float* e0 = ex + (((fm * 2 + fn) * 4 + r) * 2) * 16 * 64 + lane;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        e0[q * 64] = T0[q];
-        e0[(16 + q) * 64] = T1[q];
-      }
-    }
-  __syncthreads();
-  // wave w -> output position (ro, co) of every tile: y = A^T rows (1,1,1,0) / (0,1,-1,-1).
-  // Branch-free (uniform coefficients, activation as max/min) so that the 64 LDS reads of a
-  // channel group are issued back to back instead of one round trip each.
-  const int ro = r >> 1, co = r & 1;
-  const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
-  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
-  float ssum[2][2];
-  // the lane's first output voxel; every other one is a compile-time multiple of two uniform steps
-  // away (tile row = fm*4 + (q>>2), tile column = (q&3) + 4*half), so interior blocks store with
-  // scalar offsets and no per-element predicate
-  float* ybase = yout + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
-                 n0 + col;
-  const int64_t rowstep = 2 * (int64_t)d.Wy * d.ldy, colstep = 2 * (int64_t)d.ldy;
-  const bool interior = (oh0 + 16 <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 64 <= d.Cout);
-#pragma unroll
-  for (int fn = 0; fn < 2; ++fn) {
-    const int col_n = n0 + fn * 32 + col;
-    const bool colok = col_n < d.Cout;
-    const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
-    float s1_ = 0.f, s2_ = 0.f;
-#pragma unroll
-    for (int fm = 0; fm < 2; ++fm) {
-      const float* e0 = ex + ((fm * 2 + fn) * 4 * 2 + co) * 16 * 64 + lane;
-      float t[4][16];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
-      float v[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + k3 * t[3][q] + bv;
-        v[q] = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
-      }
-      float* yb = ybase + fn * 32 + (fm * 4) * rowstep;
-      if (interior) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
-          s1_ += v[q];
-          s2_ += v[q] * v[q];
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
-          const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
-          if (ok) yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
-          s1_ += ok ? v[q] : 0.f;
-          s2_ += ok ? v[q] * v[q] : 0.f;
-        }
-      }
-    }
-    ssum[fn][0] = s1_ + __shfl_xor(s1_, 32, 64);
-    ssum[fn][1] = s2_ + __shfl_xor(s2_, 32, 64);
-  }
-  if (d.stats_mode != 0) {  // block-level sums first: one atomic per column and block
-    __syncthreads();  // everybody is done reading ex
-    float* red = smem;
-    if (half == 0) {
-#pragma unroll
-      for (int fn = 0; fn < 2; ++fn) {
-        red[((r * 2 + fn) * 2 + 0) * 32 + col] = ssum[fn][0];
-        red[((r * 2 + fn) * 2 + 1) * 32 + col] = ssum[fn][1];
-      }
-    }
-    __syncthreads();
-    if (r < 2 && half == 0) {  // wave fn sums the four row-waves' partials of its 32 columns
-      const int fn = r, col_n = n0 + fn * 32 + col;
-      if (col_n < d.Cout) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          a1 += red[((w * 2 + fn) * 2 + 0) * 32 + col];
-          a2 += red[((w * 2 + fn) * 2 + 1) * 32 + col];
-        }
-        double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
-        atomicAdd(st, (double)a1);
-        if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// Eight-wave organisation of the big-tile kernel (same tile, LDS layout, weight panel and output transform): wave =
-// (Winograd row r, tile group fm), two waves per SIMD with 128 accumulator registers each.  The four-wave kernel above
+// Eight-wave organisation of the big-tile kernel: wave =
+// (Winograd row r, tile group fm), two waves per SIMD with 128 accumulator registers each.  A four-wave kernel
 // gives one wave a whole SIMD: whatever stalls its in-order instruction stream (an LDS fragment not yet back, the
 // barrier, a weight load) idles the matrix pipe -- measured on 512->512 @ 128x16x16: 1.71 ms against 1.43 ms of MFMA
 // time + prologue / epilogue, 1.63 ms with the LDS reads removed, 1.67 ms without the barrier.  With a second resident
@@ -971,248 +656,18 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
 
 // ------------------------------------------------------------------------------------------
 // Wide-tile variant for 32-wide output-channel tiles (nnU-Net stage-0 / last decoder stage, SR
-// head): 128 Winograd tiles (32 x 16 outputs of one depth slice) x 32 channels per block, one block
-// of 16 waves per CU (wave = Winograd row x tile group, 4 accumulator tiles each).  The four tile
-// groups share every weight fragment through L1/L2, so the small-tile kernel's weight traffic per
-// MFMA from L2 (its limiter: 2 blocks/CU on different tiles) drops.  K items are 16-channel half chunks so that the 34 x 18 patch double-buffers in
-// LDS (row pitch 368 floats, even/odd column split: conflict-free fragment reads).
+// head): up to 128 Winograd tiles (32 x 16 outputs of one depth slice) x 32 channels per block.  The tile
+// groups share every weight fragment, so the small-tile kernel's weight traffic per MFMA from L2 (its
+// limiter: 2 blocks/CU on different tiles) drops.  K items are 16-channel half chunks so that the 34 x 18
+// patch double-buffers in LDS (row pitch 368 floats, even/odd column split: conflict-free fragment reads).
+// (Rounds 1-2 ran it as 16 waves of thread-level parallelism, wino_conv_w32_kernel, 0.58 of the matrix pipe;
+// the software-pipelined 8-wave kernel below replaced it: profiles/r03_ab_superseded.txt.)
 constexpr int W3_LD = 20, W3_RP = PW2 * W3_LD + 8;
-// NFM = tile groups of 32 tiles (4 tile rows) per block: 4 (32 x 16 outputs, 16 waves, one block per CU; default) or 2
-// (16 x 16 outputs, 8 waves, 64 KB of LDS: two blocks per CU, REHR_GG_W32_ONE_PER_CU not set by the caller).  Measured
-// equal (32->32 @ 128^3: 0.574 vs 0.580 ms per call, cfg-3 unchanged), like a persistent one-block-per-CU version with
-// next-tile prefetch before it (0.623 ms): the kernel's 0.58 matrix-pipe utilisation is not a per-block fixed cost.
+// NFM = tile groups of 32 tiles (4 tile rows) of the staged patch: 4 (32 x 16 outputs) or 2 (16 x 16 outputs)
 template <int NFM> struct W3 {
   static constexpr int ROWS = 8 * NFM + 2, BUF = ROWS * W3_RP, VOX = ROWS * PW2, NTHR = 256 * NFM;
   static constexpr int NXT = (VOX * 4 + NTHR - 1) / NTHR;
 };
-
-template <int NFM>
-__global__ __launch_bounds__(256 * NFM, NFM == 2 ? 2 : 1) void wino_conv_w32_kernel(const WinoParams p) {
-  constexpr int W3_BUF = W3<NFM>::BUF, W3_VOX = W3<NFM>::VOX, NTHR = W3<NFM>::NTHR;
-  const rehr_gather_gemm_desc& d = p.d;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;  // [2][W3_BUF]; reused as the exchange buffer at the end
-  constexpr int BUF = W3_BUF;
-
-  // 16 waves = 4 Winograd rows x 4 tile groups, four per SIMD: with one channel group there is no
-  // input-fragment reuse to organise in registers, so thread-level parallelism hides the latencies
-  // instead of a hand-built pipeline (the 4-wave version of this kernel issued 47 % of the MFMA peak)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = wv & 3, fm = wv >> 2;
-  const int half = lane >> 5, col = lane & 31;
-  const int n_img = blockIdx.z;
-  const int nt0 = blockIdx.y, n0 = blockIdx.y * 32;
-  int b = xcd_remap(blockIdx.x, gridDim.x);
-  const int bw_ = b % p.nb_w; b /= p.nb_w;
-  const int bh_ = b % p.nb_h;
-  const int od = b / p.nb_h;
-  const int oh0 = bh_ * (8 * NFM), ow0 = bw_ * 16;
-
-  const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
-  const float s2 = (r == 1) ? 1.f : -1.f;
-  const float rsign = (r == 2) ? -1.f : 1.f;
-  const int th_ = fm * 4 + (col >> 3), tw_ = col & 7;
-  const float* xa = Xs + (2 * th_ + i1) * W3_RP + tw_ * W3_LD + 4 * half;
-  const float* xb = Xs + (2 * th_ + i2) * W3_RP + tw_ * W3_LD + 4 * half;
-
-  // staging pieces (LDS order: 4 pieces = 16 channels per voxel slot), 3 per thread
-  constexpr int NXT = W3<NFM>::NXT;
-  int pvx[NXT];
-  uint32_t pok = 0;
-#pragma unroll
-  for (int i = 0; i < NXT; ++i) {
-    const int piece = tid + NTHR * i;
-    const int v = piece >> 2;
-    const int ph = v / PW2, slot = v - ph * PW2;
-    const int pw_ = slot < 9 ? 2 * slot : 2 * (slot - 9) + 1;
-    const int ih = oh0 + p.dh0 + ph, iw = ow0 + p.dw0 + pw_;
-    const bool ok = (piece < W3_VOX * 4) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
-    pvx[i] = ok ? ih * d.Wi + iw : 0;
-    pok |= (ok ? 1u : 0u) << i;
-  }
-  const int pq = tid & 3;
-  const uint32_t img_elems = (uint32_t)d.Di * d.Hi * d.Wi;
-  const int nhalf = (d.Cin + 15) / 16;
-  int jd_lo = d.td.count, jd_hi = -1;  // depth taps with a source slice inside the volume (block-uniform)
-  for (int j = 0; j < d.td.count; ++j) {
-    const int id = od + d.bd + d.td.off0 + d.td.offs * j;
-    if ((unsigned)id < (unsigned)d.Di) { jd_lo = min(jd_lo, j); jd_hi = max(jd_hi, j); }
-  }
-  const int items = nhalf * max(0, jd_hi - jd_lo + 1);  // (16-channel half chunk, valid depth tap)
-  struct Item { int h16, jd; };
-  auto advance = [&](Item& t) {
-    if (++t.jd > jd_hi) { t.jd = jd_lo; ++t.h16; }
-  };
-  f32x4 rx[NXT];
-  auto fetch = [&](const Item& t) {
-    const bool live = t.h16 < nhalf;
-    const int jd = t.jd;
-    const int cc = (live ? t.h16 : 0) * 16;
-    const int id = od + d.bd + d.td.off0 + d.td.offs * jd;
-    const bool first = cc < d.c1;
-    const float* src = first ? d.x1 : d.x2;
-    const uint32_t ld = (uint32_t)(first ? d.ldx1 : d.ldx2);
-    const int coff = first ? cc : cc - d.c1;
-    const uint32_t nrec = img_elems * ld * 4u;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(src) + (int64_t)n_img * img_elems * ld, 0, nrec, 0x00020000);
-    const bool dok = live & ((unsigned)id < (unsigned)d.Di) & ((cc + pq * 4) < d.Cin);
-    const uint32_t base = (uint32_t)(id * d.Hi * d.Wi) * ld * 4u + (uint32_t)(coff + pq * 4) * 4u;
-#pragma unroll
-    for (int i = 0; i < NXT; ++i) {
-      const bool ok = dok & ((pok >> i) & 1u);
-      const uint32_t off = base + (uint32_t)pvx[i] * ld * 4u;
-      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : nrec, 0, 0));
-    }
-  };
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NXT; ++i) {
-      const int piece = tid + NTHR * i;
-      const int v = piece >> 2, row = (v * 3641) >> 16;  // v / 18 for v < 1024
-      if (piece < W3_VOX * 4) *reinterpret_cast<f32x4*>(Xs + buf + v * W3_LD + row * 8 + pq * 4) = rx[i];
-    }
-  };
-
-  // weight fragments (fragment-ordered panel [jd][xi][Npad/32][kchunks32][kk 4][lane][4]): scalar offsets
-  const __amdgpu_buffer_rsrc_t rsu =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up), 0, p.up_bytes, 0x00020000);
-  const int NT = d.Npad / 32;
-  const uint32_t xi_stride = (uint32_t)NT * p.kchunks * 4096u, nt_stride = (uint32_t)p.kchunks * 4096u;
-  const uint32_t ulane = (uint32_t)lane * 16u, ubase = (uint32_t)(r * 4) * xi_stride + (uint32_t)nt0 * nt_stride;
-  auto load_u = [&](const Item& t, const int kkl, f32x4 (&ub)[4]) {
-    const int h16 = t.h16 < nhalf ? t.h16 : 0;  // (one item past the end is requested, never used)
-    const uint32_t base = ubase + (uint32_t)(t.jd * 16) * xi_stride +
-                          (uint32_t)((h16 >> 1) * 4 + (h16 & 1) * 2 + kkl) * 1024u;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      ub[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, base + c * xi_stride, 0));
-  };
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
-
-  auto kstep = [&](int buf, const int kkl, const f32x4 (&ub)[4]) {
-    f32x4 R[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8);
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * W3_LD + kkl * 8);
-      R[j] = a + bq * s2;
-    }
-    f32x4 v[4];
-    v[0] = R[0] - R[2];
-    v[1] = R[1] + R[2];
-    v[2] = R[1] - R[2];  // negated column, undone at the output
-    v[3] = R[1] - R[3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
-  };
-
-  f32x4 u0[4], u1[4];
-  Item ci = {0, min(jd_lo, d.td.count - 1)}, ni = ci;
-  fetch(ci);
-  load_u(ci, 0, u0);
-  stage(0);
-  __syncthreads();
-  for (int it = 0; it < items; ++it) {
-    const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
-    advance(ni);
-    fetch(ni);
-    load_u(ci, 1, u1);
-    kstep(cur, 0, u0);
-    load_u(ni, 0, u0);
-    kstep(cur, 1, u1);
-    stage(nxt);
-    ci = ni;
-    __syncthreads();
-  }
-
-  // ---- output transform: columns in registers, rows across the 4 row-waves of a tile group through LDS
-  float* ex = smem;  // [fm][r][c'][q][lane]
-  {
-    const f32x16 T0 = (acc[0] + acc[1] - acc[2]) * rsign;
-    const f32x16 T1 = (acc[1] + acc[2] - acc[3]) * rsign;
-    float* e0 = ex + ((fm * 4 + r) * 2) * 16 * 64 + lane;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      e0[q * 64] = T0[q];
-      e0[(16 + q) * 64] = T1[q];
-    }
-  }
-  __syncthreads();
-  const int ro = r >> 1, co = r & 1;
-  const float k0 = ro == 0 ? 1.f : 0.f, k2 = ro == 0 ? 1.f : -1.f, k3 = ro == 0 ? 0.f : -1.f;
-  const float neg_slope = d.act == REHR_ACT_NONE ? 1.f : (d.act == REHR_ACT_RELU ? 0.f : d.slope);
-  float* ybase = d.y + ((((int64_t)n_img * d.Dy + od) * d.Hy + (oh0 + ro)) * d.Wy + (ow0 + co + 8 * half)) * d.ldy +
-                 n0 + col;
-  const int64_t rowstep = 2 * (int64_t)d.Wy * d.ldy, colstep = 2 * (int64_t)d.ldy;
-  const bool interior = (oh0 + 8 * NFM <= d.Lh) & (ow0 + 16 <= d.Lw) & (n0 + 32 <= d.Cout);
-  const int col_n = n0 + col;
-  const bool colok = col_n < d.Cout;
-  const float bv = (d.bias != nullptr && colok) ? d.bias[col_n] : 0.f;
-  float s1_ = 0.f, s2_ = 0.f;
-  {
-    const float* e0 = ex + (fm * 4 * 2 + co) * 16 * 64 + lane;
-    float t[4][16];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) t[rr][q] = e0[(rr * 32 + q) * 64];
-    float v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float yv = k0 * t[0][q] + t[1][q] + k2 * t[2][q] + k3 * t[3][q] + bv;
-      v[q] = fmaxf(yv, 0.f) + neg_slope * fminf(yv, 0.f);
-    }
-    float* yb = ybase + (fm * 4) * rowstep;
-    if (interior) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
-        s1_ += v[q];
-        s2_ += v[q] * v[q];
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int oh = oh0 + 2 * (fm * 4 + (q >> 2)) + ro, ow = ow0 + 2 * ((q & 3) + 4 * half) + co;
-        const bool ok = colok & (oh < d.Lh) & (ow < d.Lw);
-        if (ok) yb[(q >> 2) * rowstep + (q & 3) * colstep] = v[q];
-        s1_ += ok ? v[q] : 0.f;
-        s2_ += ok ? v[q] * v[q] : 0.f;
-      }
-    }
-  }
-  if (d.stats_mode != 0) {  // block-level sums first: one atomic per column and block
-    s1_ += __shfl_xor(s1_, 32, 64);
-    s2_ += __shfl_xor(s2_, 32, 64);
-    __syncthreads();  // everybody is done reading ex
-    float* red = smem;  // [wave 4 NFM][2][32]
-    if (half == 0) {
-      red[(wv * 2 + 0) * 32 + col] = s1_;
-      red[(wv * 2 + 1) * 32 + col] = s2_;
-    }
-    __syncthreads();
-    if (wv == 0 && half == 0 && colok) {
-      float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4 * NFM; ++w) {
-        a1 += red[(w * 2 + 0) * 32 + col];
-        a2 += red[(w * 2 + 1) * 32 + col];
-      }
-      double* st = d.stats + ((int64_t)n_img * d.Cout + col_n) * 2;
-      atomicAdd(st, (double)a1);
-      if (d.stats_mode == 2) atomicAdd(st + 1, (double)a2);
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // The same 128 tiles x 32 channels block with the big-tile kernel's hand-built pipeline instead of 16 waves of
@@ -1519,12 +974,10 @@ bool w32_ok(const rehr_gather_gemm_desc& d) {
   const int64_t nb_h = (d.Lh + 15) / 16, nb_w = (d.Lw + 15) / 16;
   return nb_h * 16 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13;
 }
-// four tile groups per block (one block per CU) or two (two blocks per CU)
+// four tile groups (32 x 16 outputs) when 32-row regions tile the plane within 1.3x, else two (16 x 16 outputs)
 int w32_groups(const rehr_gather_gemm_desc& d) {
-  if (d.flags & REHR_GG_W32_ONE_PER_CU) {
-    const int64_t nb_h = (d.Lh + 31) / 32, nb_w = (d.Lw + 15) / 16;
-    if (d.Lh >= 32 && nb_h * 32 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13) return 4;
-  }
+  const int64_t nb_h = (d.Lh + 31) / 32, nb_w = (d.Lw + 15) / 16;
+  if (d.Lh >= 32 && nb_h * 32 * nb_w * 16 * 10 <= (int64_t)d.Lh * d.Lw * 13) return 4;
   return 2;
 }
 
@@ -1545,22 +998,6 @@ int launch_w32p(const WinoParams& p, const rehr_gather_gemm_desc& d, hipStream_t
   return REHR_OK;
 }
 
-template <int NFM>
-int launch_w32(const WinoParams& p, const rehr_gather_gemm_desc& d, hipStream_t stream) {
-  const size_t smem_x = (size_t)2 * W3<NFM>::BUF * sizeof(float), smem_e = (size_t)NFM * 4 * 2 * 16 * 64 * sizeof(float);
-  const size_t smem = smem_x > smem_e ? smem_x : smem_e;
-  static bool attr_set32 = false;
-  if (!attr_set32) {
-    if (hipFuncSetAttribute((const void*)wino_conv_w32_kernel<NFM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess)
-      return REHR_EHIP;
-    attr_set32 = true;
-  }
-  dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 32, d.N);
-  hipLaunchKernelGGL(wino_conv_w32_kernel<NFM>, grid, dim3(256 * NFM), smem, stream, p);
-  return REHR_OK;
-}
-
 bool big_ok(const rehr_gather_gemm_desc& d) {
   if (d.Npad % 64 || d.Lh < 16 || d.Lw < 16) return false;
   const int64_t nb_h = (d.Lh + 15) / 16, nb_w = (d.Lw + 15) / 16;
@@ -1569,7 +1006,7 @@ bool big_ok(const rehr_gather_gemm_desc& d) {
 
 }  // namespace
 
-// fragment-ordered weight transform, shared with wino_flat_conv.hip
+// fragment-ordered weight transform, shared with wino_flat8_conv.hip
 int wino_weights_frag_launch(const rehr_gather_gemm_desc& d, int kchunks, hipStream_t stream) {
   const int64_t total = (int64_t)d.td.count * d.Npad * kchunks * 32;
   int64_t blocks = (total + 255) / 256;
@@ -1640,13 +1077,11 @@ int wino_conv_split_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t 
   p.nb_w = (d0.Lw + 15) / 16;
   const size_t smem_x = (size_t)2 * BUF2 * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
   const size_t smem = smem_x > smem_e ? smem_x : smem_e;
-  const bool w8 = (d0.flags & REHR_GG_WINO_8WAVE) != 0;
-  if (hipFuncSetAttribute(w8 ? (const void*)wino_conv_big8_kernel : (const void*)wino_conv_big_kernel,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)wino_conv_big8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+      hipSuccess)
     return REHR_EHIP;
   dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d0.Ld), d0.Npad / 64, d0.N * count);
-  if (w8) hipLaunchKernelGGL(wino_conv_big8_kernel, grid, dim3(512), smem, stream, p);
-  else hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL(wino_conv_big8_kernel, grid, dim3(512), smem, stream, p);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -1673,18 +1108,12 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     const int nfm = w32_groups(d);
     p.nb_h = (d.Lh + 8 * nfm - 1) / (8 * nfm);
     p.nb_w = (d.Lw + 15) / 16;
-    int rc;
-    if (d.flags & REHR_GG_W32_PIPELINED) {
-      // few K items per block (<= 32 input channels): two half-size blocks per CU hide each other's turnover (2 %)
-      const bool two = (d.flags & REHR_GG_W32P_TWO_PER_CU) ? true : (d.flags & REHR_GG_W32P_ONE_PER_CU) ? false
-                                                                   : d.Cin * d.td.count <= 96;
-      const int g = (nfm == 4 && !two) ? 2 : 1;
-      p.nb_h = (d.Lh + 16 * g - 1) / (16 * g);
-      rc = g == 2 ? launch_w32p<2>(p, d, stream) : launch_w32p<1>(p, d, stream);
-      if (rc != REHR_OK) return rc;
-    } else {
-      rc = nfm == 4 ? launch_w32<4>(p, d, stream) : launch_w32<2>(p, d, stream);
-    }
+    // few K items per block (<= 32 input channels): two half-size blocks per CU hide each other's turnover (2 %)
+    const bool two = (d.debug_flags & REHR_DBG_GG_W32P_TWO_PER_CU) ? true
+                     : (d.debug_flags & REHR_DBG_GG_W32P_ONE_PER_CU) ? false : d.Cin * d.td.count <= 96;
+    const int g = (nfm == 4 && !two) ? 2 : 1;
+    p.nb_h = (d.Lh + 16 * g - 1) / (16 * g);
+    const int rc = g == 2 ? launch_w32p<2>(p, d, stream) : launch_w32p<1>(p, d, stream);
     if (rc != REHR_OK) return rc;
     REHR_LAUNCH_CHECK();
     return REHR_OK;
@@ -1699,26 +1128,15 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     p.nb_w = (d.Lw + 15) / 16;
     const size_t smem_x = (size_t)2 * BUF2 * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
     const size_t smem = smem_x > smem_e ? smem_x : smem_e;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)wino_conv_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 64, d.N);
+    static bool attr_set8 = false;
+    if (!attr_set8) {
+      if (hipFuncSetAttribute((const void*)wino_conv_big8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem) != hipSuccess)
         return REHR_EHIP;
-      attr_set = true;
+      attr_set8 = true;
     }
-    dim3 grid((unsigned)((int64_t)p.nb_h * p.nb_w * d.Ld), d.Npad / 64, d.N);
-    if (d.flags & REHR_GG_WINO_8WAVE) {
-      static bool attr_set8 = false;
-      if (!attr_set8) {
-        if (hipFuncSetAttribute((const void*)wino_conv_big8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-          return REHR_EHIP;
-        attr_set8 = true;
-      }
-      hipLaunchKernelGGL(wino_conv_big8_kernel, grid, dim3(512), smem, stream, p);
-    } else {
-      hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(256), smem, stream, p);
-    }
+    hipLaunchKernelGGL(wino_conv_big8_kernel, grid, dim3(512), smem, stream, p);
     REHR_LAUNCH_CHECK();
     return REHR_OK;
   }

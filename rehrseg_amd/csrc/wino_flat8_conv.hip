@@ -459,8 +459,8 @@ int launch_flat8(const Flat8Params& p, hipStream_t stream) {
 
 // tiles per block: 64 unless the 64-tile grid leaves a badly filled last round on 256 CUs and the 32-tile one does not
 int f8_pick(const rehr_gather_gemm_desc& d, const Flat8Params& p64) {
-  if (d.flags & REHR_GG_FLAT8_HALF) return 1;
-  if (d.flags & REHR_GG_FLAT8_FULL) return 2;
+  if (d.debug_flags & REHR_DBG_GG_FLAT8_HALF) return 1;
+  if (d.debug_flags & REHR_DBG_GG_FLAT8_FULL) return 2;
   const int64_t units = (int64_t)((p64.ntiles + 63) / 64) * (d.Npad / 64);
   const double c64 = (double)((units + 255) / 256);             // rounds of one 64-tile block per CU
   const int64_t u2 = (int64_t)((p64.ntiles + 31) / 32) * (d.Npad / 64), rem = u2 % 512;
@@ -471,13 +471,13 @@ int f8_pick(const rehr_gather_gemm_desc& d, const Flat8Params& p64) {
 }  // namespace
 
 int64_t wino_flat8_workspace_bytes(const rehr_gather_gemm_desc& d) {
-  if (!(d.flags & REHR_GG_FLAT8)) return 0;
+  if (d.debug_flags & REHR_DBG_GG_NO_FLAT8) return 0;
   Flat8Params p;
   return plan_flat8(d, p, 2) ? (int64_t)p.up_bytes : 0;
 }
 
 int wino_flat8_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
-  if (!(d.flags & REHR_GG_FLAT8) || !d.wino_ws) return REHR_ENOSUP;
+  if ((d.debug_flags & REHR_DBG_GG_NO_FLAT8) || !d.wino_ws) return REHR_ENOSUP;
   Flat8Params p;
   if (!plan_flat8(d, p, 2)) return REHR_ENOSUP;
   if (d.wino_ws_bytes < (int64_t)p.up_bytes || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;

@@ -40,7 +40,6 @@ struct WWParams {
   int items, items_per_split, splits;
   int a_tiles, c_tiles, Capad, Cgpad;
   int fa, fb;
-  bool two;      // 64 x 32 blocks, two per CU
   bool w8;       // 64 x 64 block of 8 waves (two wave sets)
   // narrow planes (Lw < 16, e.g. the 12x12 layers of the reference's 96x96 crops): G consecutive (sample, depth)
   // slices are laid side by side, each with a 1-column zero gutter on either side, into a virtual lattice of
@@ -532,7 +531,7 @@ bool three_taps_w(const rehr_axis_taps& t, int b) {
 }
 
 bool plan(const rehr_wgrad_desc& d, WWParams& p) {
-  if (d.flags & REHR_WGRAD_DIRECT) return false;
+  if (d.debug_flags & REHR_DBG_WGRAD_DIRECT) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (!three_taps_w(d.th, d.bh) || !three_taps_w(d.tw, d.bw)) return false;
   if (d.td.count < 1 || d.td.count > 256) return false;  // any number of depth taps (feature_fuse: 128): one grid.z each
@@ -569,7 +568,7 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   // depth-tap skipping needs one tap that reaches every output slice (it carries the bias gradient)
   p.skip = 0;
   p.bias_jd = 0;
-  for (int j = 0; j < d.td.count && !(d.flags & REHR_WGRAD_NO_TAP_SKIP); ++j) {
+  for (int j = 0; j < d.td.count && !(d.debug_flags & REHR_DBG_WGRAD_NO_TAP_SKIP); ++j) {
     const int dd = d.bd + d.td.off0 + d.td.offs * j;
     if (dd >= 0 && d.Dg - dd >= d.Ld) { p.skip = 1; p.bias_jd = j; break; }   // od_lo == 0 and od_hi == Ld
   }
@@ -579,12 +578,10 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
   }
   p.fa = (d.Ca <= 32) ? 1 : 2;  // 32-channel sides take a single 32-wide group
   p.fb = (d.Cg <= 32) ? 1 : 2;
-  // two 64 x 32 blocks per CU instead of one 64 x 64 block (REHR_WGRAD_TWO_PER_CU): a second wave per SIMD fills the
-  // issue gaps of the first; dY is then staged by both blocks of a pair
-  p.two = (d.flags & REHR_WGRAD_TWO_PER_CU) && p.fa == 2 && p.fb == 2;
-  if (p.two) p.fb = 1;
-  // REHR_WGRAD_8WAVE: the 64 x 64 block as two wave sets of 32 x 64 (8 waves, two per SIMD, one staged region)
-  p.w8 = !p.two && (d.flags & REHR_WGRAD_8WAVE) && p.fa == 2 && p.fb == 2;
+  // the 64 x 64 block runs as two wave sets of 32 x 64 (8 waves, two per SIMD, one staged region).  Tried and removed
+  // in round 3 (profiles/r03_ab_superseded.txt): two independent 64 x 32 blocks per CU (+1.9 ms per cfg-2 step: dY staged
+  // twice, 20 spilled registers) and the 4-wave 64 x 64 block (equal within noise).
+  p.w8 = p.fa == 2 && p.fb == 2;
   p.a_tiles = (d.Ca + p.fa * 32 - 1) / (p.fa * 32);
   p.c_tiles = (d.Cg + p.fb * 32 - 1) / (p.fb * 32);
   p.Capad = p.a_tiles * p.fa * 32;
@@ -599,7 +596,7 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
     return false;
   // split count: fill whole rounds of 256 single-block CUs, >= 16 stages per block
   const int tiles = p.a_tiles * p.c_tiles * d.td.count;
-  const int slots = 256 * ((p.fa * p.fb == 1 || p.two) ? 2 : 1);  // resident blocks
+  const int slots = 256 * ((p.fa * p.fb == 1) ? 2 : 1);  // resident blocks
   int best_s = 1;
   double best_eff = 0.0;
   for (int k = 1; k <= 4; ++k) {
@@ -643,10 +640,8 @@ int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
   int rc;
   const bool virt = p.G != 0;
   if (p.w8) rc = virt ? launch_ww<1, 2, true, 1, 2>(p, grid, stream) : launch_ww<1, 2, false, 1, 2>(p, grid, stream);
-  else if (p.fa == 2 && p.fb == 2) rc = virt ? launch_ww<2, 2, true>(p, grid, stream) : launch_ww<2, 2, false>(p, grid, stream);
   else if (p.fa == 1 && p.fb == 1) rc = virt ? launch_ww<1, 1, true>(p, grid, stream) : launch_ww<1, 1, false>(p, grid, stream);
   else if (p.fa == 1) rc = virt ? launch_ww<1, 2, true>(p, grid, stream) : launch_ww<1, 2, false>(p, grid, stream);
-  else if (p.two) rc = virt ? launch_ww<2, 1, true, 2>(p, grid, stream) : launch_ww<2, 1, false, 2>(p, grid, stream);
   else rc = virt ? launch_ww<2, 1, true>(p, grid, stream) : launch_ww<2, 1, false>(p, grid, stream);
   if (rc != REHR_OK) return rc;
   const int64_t total = (int64_t)d.td.count * d.Ca * d.Cg;

@@ -149,23 +149,17 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
     return out
 
 
-# Kernel selection travels in the descriptors (the library reads no environment): forward / input gradient take
-# the Winograd kernels when the descriptor carries scratch, the weight gradient unless flags has REHR_WGRAD_DIRECT.
-# Tests flip these to compare the transform-domain kernels with the direct ones.
+# Kernel selection travels in the descriptors (the library reads no environment).  With `flags` / `debug_flags` = 0
+# the library picks its measured-best kernels: forward / input gradient take the Winograd kernels when the descriptor
+# carries scratch.  The switches below set `debug_flags` bits (unstable, include/rehrseg_hip.h): tests flip them to
+# compare kernel organisations with each other (transform-domain against direct, brick against per-tap, ...).
 USE_WINOGRAD = True
-USE_WINOGRAD_WGRAD = True
-USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps
-USE_WGRAD_BRICK_8WAVE = True   # mixed precision: the brick weight-gradient kernel with eight waves per block
-USE_HALO_8WAVE = True   # mixed precision: the halo-brick kernel with eight waves per block
+USE_WINOGRAD_WGRAD = True   # False -> REHR_DBG_WGRAD_DIRECT
+USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps (False -> REHR_DBG_GG_NO_HALO)
 USE_WGRAD_TAP_SKIP = True   # Winograd weight gradient: a depth tap walks only the slices whose source slice exists
-USE_WGRAD_8WAVE = True   # Winograd weight gradient: the 64 x 64 block as 8 waves (two per SIMD)
-USE_WGRAD_TWO_PER_CU = False  # Winograd weight gradient: two 64 x 32 blocks per CU for the >= 64-channel layers
-USE_W32_TWO_PER_CU = False # fp32 32-channel-tile Winograd kernel: two 512-thread blocks per CU (False: one of 1024)
-USE_W32_PIPELINED = True   # fp32 32-channel-tile Winograd kernel: 8 waves, software-pipelined (wino_conv_w32p_kernel)
 W32P_BLOCKS = 0   # 0: the library picks; 1 / 2 force two 256-thread blocks per CU / one 512-thread block (tests, A/B)
 USE_WINO_FLAT8 = True   # fp32 Winograd on planes that 16 x 16 regions tile badly: wino_flat8_conv_kernel
 WINO_FLAT8_TILES = 0    # 0: the library picks 32 or 64 tiles per block; 1 / 2 force 32 / 64 (tests, A/B)
-USE_WINO_8WAVE = True   # fp32 big-tile Winograd kernel: two waves per SIMD (wino_conv_big8_kernel)
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
 wino_launches = 0  # contractions handed to the Winograd kernels so far (tests look at this)
 
@@ -195,19 +189,21 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d.tile_d, d.tile_h, d.tile_w = tile
     d.wino_ws, d.wino_ws_bytes = None, 0
     d.flags = 0
+    d.debug_flags = 0
     keep = None
     if x1.dtype == torch.bfloat16:
         if wp.dtype != torch.bfloat16 or (x2 is not None and x2.dtype != torch.bfloat16):
             raise L.RehrsegHipError("mixed-precision gather-GEMM: x1, x2 and the packed weights must all be bfloat16")
         if bias is not None and bias.dtype != torch.float32:
             raise L.RehrsegHipError("bias stays float32")
-        d.flags = ((L.GG_Y_F32 if y.dtype == torch.float32 else 0) | (0 if USE_HALO_BF16 else L.GG_NO_HALO) |
-                   (L.GG_HALO_8WAVE if USE_HALO_8WAVE else 0))
+        d.flags = L.GG_Y_F32 if y.dtype == torch.float32 else 0
+        d.debug_flags = 0 if USE_HALO_BF16 else L.DBG_GG_NO_HALO
     elif wp.dtype != torch.float32 or y.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
         raise L.RehrsegHipError("fp32 gather-GEMM: every operand must be float32")
     elif USE_WINOGRAD and tile[0] >= 0:
-        d.flags = ((L.GG_WINO_8WAVE if USE_WINO_8WAVE else 0) | (0 if USE_W32_TWO_PER_CU else L.GG_W32_ONE_PER_CU) |
-                   (L.GG_FLAT8 if USE_WINO_FLAT8 else 0) | (L.GG_W32_PIPELINED if USE_W32_PIPELINED else 0) | {1: L.GG_W32P_TWO_PER_CU, 2: L.GG_W32P_ONE_PER_CU}.get(W32P_BLOCKS, 0) | {1: L.GG_FLAT8_HALF, 2: L.GG_FLAT8_FULL}.get(WINO_FLAT8_TILES, 0))
+        d.debug_flags = ((0 if USE_WINO_FLAT8 else L.DBG_GG_NO_FLAT8) |
+                         {1: L.DBG_GG_W32P_TWO_PER_CU, 2: L.DBG_GG_W32P_ONE_PER_CU}.get(W32P_BLOCKS, 0) |
+                         {1: L.DBG_GG_FLAT8_HALF, 2: L.DBG_GG_FLAT8_FULL}.get(WINO_FLAT8_TILES, 0))
         nbytes = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
         if nbytes > 0:
             keep = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
@@ -297,9 +293,8 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     d.dst_sa, d.dst_sc, d.dst_st = dst_strides
     d.accumulate = int(accumulate)
     d.dbias = _ptr(dbias)
-    d.flags = ((0 if USE_WINOGRAD_WGRAD else L.WGRAD_DIRECT) | (L.WGRAD_TWO_PER_CU if USE_WGRAD_TWO_PER_CU else 0) |
-               (L.WGRAD_8WAVE if USE_WGRAD_8WAVE else 0) | (L.WGRAD_BRICK_8WAVE if USE_WGRAD_BRICK_8WAVE else 0) |
-               (0 if USE_WGRAD_TAP_SKIP else L.WGRAD_NO_TAP_SKIP))
+    d.flags = 0
+    d.debug_flags = (0 if USE_WINOGRAD_WGRAD else L.DBG_WGRAD_DIRECT) | (0 if USE_WGRAD_TAP_SKIP else L.DBG_WGRAD_NO_TAP_SKIP)
     lib = L.load()
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
     if bf16:

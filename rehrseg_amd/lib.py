@@ -16,23 +16,17 @@ LIB_PATH = os.environ.get("REHRSEG_HIP_LIB") or os.path.join(_HERE, "librehrseg_
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rehrseg_hip.h")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-ABI_VERSION = 2
-WGRAD_DIRECT = 1  # rehr_wgrad_desc.flags
-WGRAD_TWO_PER_CU = 2
-WGRAD_8WAVE = 4
-WGRAD_BRICK_8WAVE = 8
-WGRAD_NO_TAP_SKIP = 16
-GG_Y_F32 = 1      # rehr_gather_gemm_desc.flags
-GG_NO_HALO = 2
-GG_WINO_8WAVE = 4
-GG_W32_ONE_PER_CU = 8
-GG_HALO_8WAVE = 16
-GG_FLAT8 = 32
-GG_FLAT8_HALF = 64
-GG_FLAT8_FULL = 128
-GG_W32_PIPELINED = 256
-GG_W32P_TWO_PER_CU = 512
-GG_W32P_ONE_PER_CU = 1024
+ABI_VERSION = 3
+GG_Y_F32 = 1            # rehr_gather_gemm_desc.flags
+# debug_flags (unstable; tests and A/B tools only -- 0 selects the measured-best kernels)
+DBG_WGRAD_DIRECT = 1    # rehr_wgrad_desc.debug_flags
+DBG_WGRAD_NO_TAP_SKIP = 2
+DBG_GG_NO_HALO = 1      # rehr_gather_gemm_desc.debug_flags
+DBG_GG_NO_FLAT8 = 2
+DBG_GG_FLAT8_HALF = 4
+DBG_GG_FLAT8_FULL = 8
+DBG_GG_W32P_TWO_PER_CU = 16
+DBG_GG_W32P_ONE_PER_CU = 32
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p
@@ -62,7 +56,7 @@ class GatherGemmDesc(C.Structure):
         ("stats", _vp), ("stats_mode", _i32),
         ("tile_d", _i32), ("tile_h", _i32), ("tile_w", _i32),
         ("wino_ws", _vp), ("wino_ws_bytes", _i64),
-        ("flags", _i32),
+        ("flags", _i32), ("debug_flags", _i32),
     ]
 
 
@@ -78,7 +72,7 @@ class WgradDesc(C.Structure):
         ("accumulate", _i32),
         ("workspace", _vp), ("workspace_bytes", _i64),
         ("dbias", _vp),
-        ("flags", _i32),
+        ("flags", _i32), ("debug_flags", _i32),
     ]
 
 

@@ -8,9 +8,13 @@
          tests/golden/conditioning_cfg4.json by a REHR_PARITY_FP64=1 run of this very test).
   cfg-5  the same step at 1x1x160^3 under ops.mixed_precision() against the fp32 HIP step on the same inputs (the HIP
          fp32 path is what the cfg-4 test and tests/test_full_size_oracle_gpu.py tie to the CPU path): finite, loss
-         within 2e-2, teacher features within 2e-2 l2-rel, LR / HR label agreement reported and >= 99 % / exact
-         wherever the fp32 logit margin exceeds 5 % of the logit scale, gradient distances reported with the toy-plan
-         calibration of tests/test_mixed_steps_gpu.py as the bar (bf16 rounding through 22 layers: <= 0.35 l2-rel).
+         within 1e-3, teacher features within 1e-2 l2-rel, logits within 3e-2 l2-rel, LR / HR label agreement reported
+         and >= 99 % / exact wherever the fp32 logit margin exceeds 5 % of the logit scale.  Gradients: every tensor's
+         bf16-vs-fp32 distance is reported; the bar is by depth, as calibrated by the full-depth-plan test of
+         tests/test_mixed_steps_gpu.py (there the bf16-emulating fp64 oracle shows what rounding ALONE does to this
+         randomly initialised 22-layer InstanceNorm stack: percent at the heads, tens of percent at the bottom stages,
+         whose gradients are small residuals of cancelling sums): heads / last decoder stage <= 2e-2, everything
+         <= 0.6 l2-rel with cosine similarity >= 0.8.
 
 Reference: train_all.py:85-112 (get_intermediate_features), :519-556 (the loop).
 """
@@ -157,13 +161,18 @@ def test_cfg5_joint_step_160cube_bf16_against_the_fp32_step():
     for k, ref in g32.items():
         if k.endswith("conv.bias") and "sr_head" not in k or float(ref.norm()) == 0.0:
             continue
-        rows.append((k, _l2rel(g16[k], ref)))
+        cos = float((g16[k].double() * ref.double()).sum() / (g16[k].double().norm() * ref.double().norm()))
+        rows.append((k, _l2rel(g16[k], ref), cos))
     rows.sort(key=lambda r: -r[1])
     summary["gradient_l2rel_worst"] = rows[:6]
     summary["gradient_l2rel_median"] = rows[len(rows) // 2][1]
+    summary["gradient_cosine_min"] = min(r[2] for r in rows)
     print("[cfg5] " + json.dumps(summary))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_cfg5.json"), "w") as f:
         json.dump({"summary": summary, "gradients": rows}, f, indent=1)
-    assert summary["loss_rel"] <= 2e-2 and summary["teacher_features_l2rel"] <= 2e-2
-    assert rows[0][1] <= 0.35, rows[:6]
+    assert summary["loss_rel"] <= 1e-3 and summary["teacher_features_l2rel"] <= 1e-2
+    assert summary["logits_l2rel_lr"] <= 3e-2 and summary["logits_l2rel_hr"] <= 3e-2
+    for k, e, cos in rows:
+        shallow = any(t in k for t in ("sr_head", "seg_layers", "distiller", "decoder.stages.4"))
+        assert e <= (2e-2 if shallow else 0.6) and cos >= 0.8, (k, e, cos)

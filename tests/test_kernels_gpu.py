@@ -166,8 +166,8 @@ def test_winograd_flat8_statistics_and_concat(tiles, monkeypatch):
          [x, x2, w, b, ga, be], [True, True, True, False, True, True])
 
 
-def test_winograd_flat_conv_previous_kernel(monkeypatch):
-    """wino_flat_conv_kernel (16 waves, whole planes staged) stays selectable: REHR_GG_FLAT8 off."""
+def test_small_planes_without_the_flattened_tile_kernel(monkeypatch):
+    """REHR_DBG_GG_NO_FLAT8: the 12 x 12 planes fall back to the region / direct kernels -- same results."""
     from rehrseg_amd import hip_backend
     monkeypatch.setattr(hip_backend, "USE_WINO_FLAT8", False)
     x = _mk(32, 64, 4, 12, 12, seed=190)
@@ -538,88 +538,52 @@ def test_cosine_distance_loss_fused():
 
 # ----------------------------------------------------------------------------- kernel-organisation variants
 @pytest.mark.parametrize("Cin,Cout,dims", [(64, 64, (5, 40, 48)), (96, 128, (3, 32, 32)), (64, 192, (4, 32, 48))])
-def test_winograd_eight_wave_kernel_is_bit_identical(Cin, Cout, dims):
-    """wino_conv_big8_kernel (two waves per SIMD, default) against wino_conv_big_kernel (one): same tile, same panel,
-    same summation order -> the same bits, statistics epilogue included."""
+def test_winograd_big_tile_kernel_against_direct_kernel_and_fp64(Cin, Cout, dims):
+    """wino_conv_big8_kernel (64 tiles x 64 channels, two waves per SIMD) against the direct gather-GEMM kernel and
+    fp64, statistics epilogue included.  (Rounds 1-2 also carried a four-wave organisation of the same tile; it was
+    removed in round 3 after the A/B of profiles/r03_ab_superseded.txt.)"""
     from rehrseg_amd import hip_backend as hb
     x = _mk(2, Cin, *dims, seed=61).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
     w = (_mk(Cout, Cin, 3, 3, 3, seed=62) / (27 * Cin) ** 0.5).to(_dev())
     b = _mk(Cout, seed=63).to(_dev())
     cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
-    saved = hb.USE_WINO_8WAVE
+    saved = hb.USE_WINOGRAD
     try:
         out = {}
         for flag in (False, True):
-            hb.USE_WINO_8WAVE = flag
+            hb.USE_WINOGRAD = flag
             before = hb.wino_launches
             out[flag] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.01, 2)
-            assert hb.wino_launches > before
+            assert (hb.wino_launches > before) == flag
     finally:
-        hb.USE_WINO_8WAVE = saved
-    assert torch.equal(out[True][0], out[False][0])
-    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-6, atol=1e-6)   # fp32 block partials: other grouping
+        hb.USE_WINOGRAD = saved
+    ref = F.leaky_relu(F.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), 1, 1), 0.01)
+    _close(out[True][0], ref)
+    _close(out[True][0], out[False][0].double().cpu(), 2e-5)
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-4)
 
 
-def test_winograd_w32_two_per_cu_variant():
-    """wino_conv_w32_kernel<2> (two 512-thread blocks per CU) against <4> (one of 1024): same arithmetic per tile."""
-    from rehrseg_amd import hip_backend as hb
-    x = _mk(2, 32, 4, 64, 48, seed=64).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
-    w = (_mk(32, 32, 3, 3, 3, seed=65) / (27 * 32) ** 0.5).to(_dev())
-    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
-    saved = hb.USE_W32_TWO_PER_CU
-    try:
-        out = {}
-        for flag in (False, True):
-            hb.USE_W32_TWO_PER_CU = flag
-            out[flag] = ops.conv_forward(x, None, w, None, cfg, 0, 0.0, 2)
-    finally:
-        hb.USE_W32_TWO_PER_CU = saved
-    assert torch.equal(out[True][0], out[False][0])
-
-
-@pytest.mark.parametrize("blocks", [1, 2])
 @pytest.mark.parametrize("dims,Cin,Cout", [((2, 4, 64, 48), 32, 32), ((1, 3, 60, 30), 48, 96), ((1, 2, 33, 50), 48, 32)])
-def test_winograd_w32_pipelined_variant(dims, Cin, Cout, blocks, monkeypatch):
-    """wino_conv_w32p_kernel (8 waves, software pipeline) against wino_conv_w32_kernel<4> (16 waves): the same products
-    in the same order per accumulator -> the same bits, statistics included; ragged regions and a half last chunk."""
+def test_winograd_w32_pipelined_kernel(dims, Cin, Cout, monkeypatch):
+    """wino_conv_w32p_kernel (32-channel tiles, 8 waves, software pipeline): its two block shapes (two 256-thread blocks
+    per CU / one 512-thread block) do the same products in the same order per accumulator -> the same bits, statistics
+    included; both against fp64; ragged regions and a half last chunk."""
     from rehrseg_amd import hip_backend as hb
-    monkeypatch.setattr(hb, "W32P_BLOCKS", blocks)   # 1: two 256-thread blocks per CU, 2: one 512-thread block
     N, D, H, W = dims
     x = _mk(N, Cin, D, H, W, seed=164).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
     w = (_mk(Cout, Cin, 3, 3, 3, seed=165) / (27 * Cin) ** 0.5).to(_dev())
     b = _mk(Cout, seed=166).to(_dev())
     cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
-    saved = hb.USE_W32_PIPELINED
-    try:
-        out = {}
-        for flag in (False, True):
-            hb.USE_W32_PIPELINED = flag
-            out[flag] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.01, 2)
-    finally:
-        hb.USE_W32_PIPELINED = saved
-    assert torch.equal(out[True][0], out[False][0])
-    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-6, atol=1e-6)
+    out = {}
+    for blocks in (1, 2):
+        monkeypatch.setattr(hb, "W32P_BLOCKS", blocks)
+        before = hb.wino_launches
+        out[blocks] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.01, 2)
+        assert hb.wino_launches > before
+    assert torch.equal(out[1][0], out[2][0])
+    torch.testing.assert_close(out[1][1], out[2][1], rtol=1e-6, atol=1e-6)
     ref = F.leaky_relu(F.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), 1, 1), 0.01)
-    _close(out[True][0], ref)
-
-
-def test_winograd_wgrad_two_per_cu_variant():
-    """REHR_WGRAD_TWO_PER_CU (two 64 x 32 blocks per CU) against the 64 x 64 blocking: same products, another split."""
-    from rehrseg_amd import hip_backend as hb
-    x = _mk(2, 64, 4, 32, 32, seed=66).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
-    dy = _mk(2, 128, 4, 32, 32, seed=67).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
-    w = _mk(128, 64, 3, 3, 3, seed=68).to(_dev())
-    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
-    saved = hb.USE_WGRAD_TWO_PER_CU
-    try:
-        out = {}
-        for flag in (False, True):
-            hb.USE_WGRAD_TWO_PER_CU = flag
-            out[flag] = ops.conv_wgrad(dy, x, None, w, cfg, True)
-    finally:
-        hb.USE_WGRAD_TWO_PER_CU = saved
-    torch.testing.assert_close(out[True][0], out[False][0], rtol=1e-5, atol=1e-4)
-    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-4)
+    _close(out[1][0], ref)
 
 
 @pytest.mark.parametrize("dims,Ca,Cg,K", [((16, 4, 12, 12), 128, 64, (3, 3, 3)),   # side-by-side mode, depth-major groups
@@ -654,24 +618,30 @@ def test_winograd_wgrad_tap_skip(dims, Ca, Cg, K):
     _close(out[True][1], rb)
 
 
-def test_winograd_wgrad_eight_wave_variant():
-    """REHR_WGRAD_8WAVE (the 64 x 64 block as two wave sets, two waves per SIMD) against the four-wave block: the same
-    products in the same order per accumulator -> the same bits."""
+def test_winograd_wgrad_64x64_block_against_direct_kernel_and_fp64():
+    """The 64 x 64 block of wino_wgrad_kernel (two wave sets, two waves per SIMD) against the direct slab kernel and fp64."""
     from rehrseg_amd import hip_backend as hb
     x = _mk(2, 64, 4, 32, 48, seed=71).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
     dy = _mk(2, 128, 4, 32, 48, seed=72).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
     w = _mk(128, 64, 3, 3, 3, seed=73).to(_dev())
     cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
-    saved = hb.USE_WGRAD_8WAVE
+    saved = hb.USE_WINOGRAD_WGRAD
     try:
         out = {}
         for flag in (False, True):
-            hb.USE_WGRAD_8WAVE = flag
+            hb.USE_WINOGRAD_WGRAD = flag
+            before = hb.wino_wgrad_launches
             out[flag] = ops.conv_wgrad(dy, x, None, w, cfg, True)
+            assert (hb.wino_wgrad_launches - before == 1) == flag
     finally:
-        hb.USE_WGRAD_8WAVE = saved
-    assert torch.equal(out[True][0], out[False][0])
-    assert torch.equal(out[True][1], out[False][1])
+        hb.USE_WINOGRAD_WGRAD = saved
+    _close(out[True][0], out[False][0].double().cpu(), 1e-5)
+    _close(out[True][1], out[False][1].double().cpu(), 1e-5)
+    xr, wr = x.double().cpu().requires_grad_(), w.double().cpu().requires_grad_()
+    br = torch.zeros(128, dtype=torch.float64, requires_grad=True)
+    rw, rb = torch.autograd.grad(F.conv3d(xr, wr, br, 1, 1), [wr, br], dy.double().cpu())
+    _close(out[True][0], rw)
+    _close(out[True][1], rb)
 
 
 @pytest.mark.parametrize("K,D,N,hw", [(16, 4, 2, (24, 40)), (4, 3, 1, (7, 9)), (8, 8, 3, (5, 5)), (32, 2, 2, (33, 17))])

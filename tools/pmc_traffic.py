@@ -7,7 +7,7 @@ Units follow /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB; o
 import csv, json, re, sys
 from collections import defaultdict
 
-FAMILIES = [("wino_conv_big", r"wino_conv_big_kernel"), ("wino_conv_w32", r"wino_conv_w32_kernel"),
+FAMILIES = [("wino_conv_big", r"wino_conv_big8_kernel"), ("wino_conv_w32", r"wino_conv_w32p_kernel"),
             ("wino_conv_small", r"wino_conv_kernel"), ("wino22_conv", r"wino22_conv_kernel"),
             ("wino22_wgrad", r"wino22_wgrad_kernel"), ("wino_wgrad", r"wino_wgrad_kernel"), ("halo_conv", r"halo_conv_kernel"),
             ("gather_gemm", r"gather_gemm(_multi)?_kernel"), ("wgrad_slab", r"wgrad_kernel<"),
