@@ -117,6 +117,9 @@ typedef struct {
 /* fp32: the 32-channel-tile Winograd kernel forced to two 256-thread blocks per CU / one 512-thread block */
 #define REHR_DBG_GG_W32P_TWO_PER_CU 16
 #define REHR_DBG_GG_W32P_ONE_PER_CU 32
+/* multi-phase launches: blockIdx.z = phase (each phase streams the source once) instead of the phases of a lattice tile
+ * as consecutive blocks of one XCD */
+#define REHR_DBG_GG_NO_INTERLEAVE 64
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
@@ -244,6 +247,9 @@ int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* d, void* stream);
 int rehr_im2col_f32(const rehr_direct_conv_desc* d, float* out, int32_t Kpad,
                     void* stream);
 int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc* d);
+/* 1 when rehr_conv_small_cin_wgrad_f32 takes this shape on the matrix cores (thin_cin_conv.hip: C_out 32 / 64,
+ * 1x3x3 / 3x3x3 / (3,7,7) taps, stride_w <= 2) -- dY and x are then each read once, no im2col columns */
+int rehr_conv_small_cin_wgrad_on_mfma(const rehr_direct_conv_desc* d);
 /* dw (Cout,Cin,KD,KH,KW) = sum_{n,o} dY[n,o,co] * x[n,o*s-p+k,ci]; dbias optional */
 int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* d, float* dw,
                                   float* dbias, float* workspace,

@@ -214,6 +214,9 @@ int wgrad_blocks(const rehr_direct_conv_desc& d, int64_t* vpb) {
 }  // namespace
 
 int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream);   // thin_cin_conv.hip: fp32 matrix cores
+int64_t thin_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc& d);
+int thin_cin_wgrad_try(const rehr_direct_conv_desc& d, float* dw, float* dbias, float* workspace, int64_t workspace_bytes,
+                       hipStream_t stream);
 
 extern "C" int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* dp, void* stream) {
   if (!dp || !small_cin_ok(*dp)) return REHR_EINVAL;
@@ -255,6 +258,10 @@ extern "C" int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* dp, fl
                                              float* workspace, int64_t workspace_bytes, void* stream) {
   if (!dp || !small_cin_ok(*dp) || !dw || !workspace) return REHR_EINVAL;
   const rehr_direct_conv_desc& d = *dp;
+  {
+    const int rc = thin_cin_wgrad_try(d, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);   // matrix cores
+    if (rc != REHR_ENOSUP) return rc;
+  }
   const int T = d.KD * d.KH * d.KW;
   int64_t vpb;
   const int blocks = wgrad_blocks(d, &vpb);
@@ -274,8 +281,16 @@ extern "C" int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* dp, fl
   return REHR_OK;
 }
 
+extern "C" int rehr_conv_small_cin_wgrad_on_mfma(const rehr_direct_conv_desc* dp) {
+  return dp && small_cin_ok(*dp) && thin_cin_wgrad_workspace_bytes(*dp) > 0;
+}
+
 extern "C" int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc* dp) {
   if (!dp) return REHR_EINVAL;
+  {
+    const int64_t b = small_cin_ok(*dp) ? thin_cin_wgrad_workspace_bytes(*dp) : 0;
+    if (b > 0) return b;
+  }
   int64_t vpb;
   const int blocks = wgrad_blocks(*dp, &vpb);
   const int T = dp->KD * dp->KH * dp->KW;

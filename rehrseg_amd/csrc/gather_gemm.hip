@@ -45,7 +45,7 @@ struct GGParams {
 //             halves LDS so the narrow-N tiles run 3 blocks per CU, whose MFMA phases fill each
 //             other's barrier bubbles.
 template <int BM, int BN, int WGM, int WGN, int LDSBUF>
-__device__ __forceinline__ void gather_gemm_body(const GGParams& p, const int nblocks) {
+__device__ __forceinline__ void gather_gemm_body(const GGParams& p, const int nblocks, const int logical_in = -1) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int FM = WTM / 32, FN = WTN / 32;
   constexpr int AROWS = BM / 32, BROWS = BN / 32;  // rows per thread per tile
@@ -62,7 +62,7 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p, const int nb
   const int wm = wave / WGN, wn = wave % WGN;
   const int n_img = blockIdx.y;
 
-  const int logical = xcd_remap(blockIdx.x, nblocks);
+  const int logical = logical_in >= 0 ? logical_in : xcd_remap(blockIdx.x, nblocks);
   const int mt = logical / p.n_tiles;
   const int nt = logical - mt * p.n_tiles;
   const int n0 = nt * BN;
@@ -343,12 +343,33 @@ constexpr int MAX_PHASES = 8;
 // Several launches that differ only in lattice / taps / destination offset (the stride
 // phases of one transposed conv or strided input gradient) share ONE grid: blockIdx.z picks
 // the phase, so four quarter-size launches fill the chip like one full-size launch.
+// interleave != 0 (all phases have the same tile counts -- kernel = stride transposed convolutions, input gradients
+// of strided convolutions on even extents): a 1-D grid in which the `count` phases of one lattice tile are CONSECUTIVE
+// blocks of ONE XCD, so the tile's source rows come from HBM once and from that XCD's L2 for the other phases (with
+// blockIdx.z = phase the whole source tensor streamed from HBM once per phase: the 64 -> 32 transposed convolution of
+// cfg-3 moved 1.6 GB for 0.67 GB of algorithmic traffic).
 struct GGMulti {
   GGParams ph[MAX_PHASES];
+  int interleave, count, no_interleave;
 };
+
+// block b of the interleaved grid -> (phase, logical tile); false: padding block
+__device__ __forceinline__ bool interleaved_block(int b, int m_tiles, int n_tiles, int count, int& phase, int& logical) {
+  const int xcd = b & 7, j = b >> 3, per = count * n_tiles;
+  const int mt = (j / per) * 8 + xcd, rem = j % per;
+  phase = rem / n_tiles;
+  logical = mt * n_tiles + (rem - phase * n_tiles);
+  return mt < m_tiles;
+}
 
 template <int BM, int BN, int WGM, int WGN, int LDSBUF>
 __global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_multi_kernel(const GGMulti pm) {
+  if (pm.interleave) {
+    int phase, logical;
+    if (!interleaved_block((int)blockIdx.x, pm.ph[0].m_tiles, pm.ph[0].n_tiles, pm.count, phase, logical)) return;
+    gather_gemm_body<BM, BN, WGM, WGN, LDSBUF>(pm.ph[phase], 0, logical);
+    return;
+  }
   const GGParams& p = pm.ph[blockIdx.z];
   const int nb = p.m_tiles * p.n_tiles;
   if ((int)blockIdx.x >= nb) return;  // block-uniform: phases have different tile counts
@@ -380,11 +401,18 @@ int launch_gg(const GGMulti& pm, int count, hipStream_t stream) {
     hipLaunchKernelGGL(kern1, dim3(p.m_tiles * p.n_tiles, p.d.N, 1), dim3(NTHREADS), smem, stream, p);
   } else {
     int nb = 0;
+    bool uniform = true;
     for (int i = 0; i < count; ++i) {
       const int n = pm.ph[i].m_tiles * pm.ph[i].n_tiles;
       nb = n > nb ? n : nb;
+      uniform = uniform && pm.ph[i].m_tiles == pm.ph[0].m_tiles && pm.ph[i].n_tiles == pm.ph[0].n_tiles;
     }
-    hipLaunchKernelGGL(kernm, dim3(nb, pm.ph[0].d.N, count), dim3(NTHREADS), smem, stream, pm);
+    GGMulti pmi = pm;
+    pmi.count = count;
+    const int64_t gx = (int64_t)((pm.ph[0].m_tiles + 7) / 8) * 8 * count * pm.ph[0].n_tiles;
+    pmi.interleave = (uniform && !pm.no_interleave && gx < (1ll << 31)) ? 1 : 0;
+    if (pmi.interleave) hipLaunchKernelGGL(kernm, dim3((unsigned)gx, pm.ph[0].d.N, 1), dim3(NTHREADS), smem, stream, pmi);
+    else hipLaunchKernelGGL(kernm, dim3(nb, pm.ph[0].d.N, count), dim3(NTHREADS), smem, stream, pmi);
   }
   REHR_LAUNCH_CHECK();
   return REHR_OK;
@@ -476,6 +504,9 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
     if (frc != REHR_ENOSUP) return frc;
   }
   GGMulti pm;
+  pm.interleave = 0;
+  pm.count = 0;
+  pm.no_interleave = (descs[0].debug_flags & REHR_DBG_GG_NO_INTERLEAVE) ? 1 : 0;
   int n = 0;
   for (int i = 0; i < count; ++i) {
     // fewer multiplications beat better tiling: Winograd first -- except for the tap-range parts of a split-K

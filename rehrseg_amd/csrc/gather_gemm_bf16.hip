@@ -37,7 +37,7 @@ struct GBParams {
 };
 
 template <int BM, int BN, int WGM, int WGN, int LDSBUF, int BK>
-__device__ __forceinline__ void gg_bf16_body(const GBParams& p, const int nblocks) {
+__device__ __forceinline__ void gg_bf16_body(const GBParams& p, const int nblocks, const int logical_in = -1) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int FM = WTM / 32, FN = WTN / 32;
   constexpr int TPR = BK / 8;                 // threads per row (16 bytes = 8 channels each)
@@ -57,7 +57,7 @@ __device__ __forceinline__ void gg_bf16_body(const GBParams& p, const int nblock
   const int wm = wave / WGN, wn = wave % WGN;
   const int n_img = blockIdx.y;
 
-  const int logical = xcd_remap(blockIdx.x, nblocks);
+  const int logical = logical_in >= 0 ? logical_in : xcd_remap(blockIdx.x, nblocks);
   const int mt = logical / p.n_tiles;
   const int nt = logical - mt * p.n_tiles;
   const int n0 = nt * BN;
@@ -319,12 +319,28 @@ __device__ __forceinline__ void gg_bf16_body(const GBParams& p, const int nblock
 }
 
 constexpr int MAX_PHASES = 8;
+// interleave: see GGMulti in gather_gemm.hip -- the phases of one lattice tile as consecutive blocks of one XCD
 struct GBMulti {
   GBParams ph[MAX_PHASES];
+  int interleave, count, no_interleave;
 };
+
+__device__ __forceinline__ bool interleaved_block_b(int b, int m_tiles, int n_tiles, int count, int& phase, int& logical) {
+  const int xcd = b & 7, j = b >> 3, per = count * n_tiles;
+  const int mt = (j / per) * 8 + xcd, rem = j % per;
+  phase = rem / n_tiles;
+  logical = mt * n_tiles + (rem - phase * n_tiles);
+  return mt < m_tiles;
+}
 
 template <int BM, int BN, int WGM, int WGN, int LDSBUF, int BK>
 __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_bf16_multi_kernel(const GBMulti pm) {
+  if (pm.interleave) {
+    int phase, logical;
+    if (!interleaved_block_b((int)blockIdx.x, pm.ph[0].m_tiles, pm.ph[0].n_tiles, pm.count, phase, logical)) return;
+    gg_bf16_body<BM, BN, WGM, WGN, LDSBUF, BK>(pm.ph[phase], 0, logical);
+    return;
+  }
   const GBParams& p = pm.ph[blockIdx.z];
   const int nb = p.m_tiles * p.n_tiles;
   if ((int)blockIdx.x >= nb) return;
@@ -354,11 +370,18 @@ int launch_gb(const GBMulti& pm, int count, hipStream_t stream) {
     hipLaunchKernelGGL(kern1, dim3(p.m_tiles * p.n_tiles, p.d.N, 1), dim3(NTHREADS), smem, stream, p);
   } else {
     int nb = 0;
+    bool uniform = true;
     for (int i = 0; i < count; ++i) {
       const int n = pm.ph[i].m_tiles * pm.ph[i].n_tiles;
       nb = n > nb ? n : nb;
+      uniform = uniform && pm.ph[i].m_tiles == pm.ph[0].m_tiles && pm.ph[i].n_tiles == pm.ph[0].n_tiles;
     }
-    hipLaunchKernelGGL(kernm, dim3(nb, pm.ph[0].d.N, count), dim3(NTHREADS), smem, stream, pm);
+    GBMulti pmi = pm;
+    pmi.count = count;
+    const int64_t gx = (int64_t)((pm.ph[0].m_tiles + 7) / 8) * 8 * count * pm.ph[0].n_tiles;
+    pmi.interleave = (uniform && !pm.no_interleave && gx < (1ll << 31)) ? 1 : 0;
+    if (pmi.interleave) hipLaunchKernelGGL(kernm, dim3((unsigned)gx, pm.ph[0].d.N, 1), dim3(NTHREADS), smem, stream, pmi);
+    else hipLaunchKernelGGL(kernm, dim3(nb, pm.ph[0].d.N, count), dim3(NTHREADS), smem, stream, pmi);
   }
   REHR_LAUNCH_CHECK();
   return REHR_OK;
@@ -444,6 +467,9 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ in, __bf16* _
 extern "C" int rehr_gather_gemm_multi_bf16(const rehr_gather_gemm_desc* descs, int32_t count, void* stream) {
   if (descs == nullptr || count < 1 || count > MAX_PHASES) return REHR_EINVAL;
   GBMulti pm;
+  pm.interleave = 0;
+  pm.count = 0;
+  pm.no_interleave = (descs[0].debug_flags & REHR_DBG_GG_NO_INTERLEAVE) ? 1 : 0;
   int n = 0;
   for (int i = 0; i < count; ++i) {
     int rc = validate(descs[i]);

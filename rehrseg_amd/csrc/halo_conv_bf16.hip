@@ -41,7 +41,6 @@ template <int NWV> struct HBW {
 };
 constexpr int BVOX = 512;
 constexpr int BN = 32;
-constexpr int MAXTAPS = 27;
 
 struct HBParams {
   rehr_gather_gemm_desc d;

@@ -30,7 +30,6 @@ constexpr int BUF = PW * RP;           // floats per slice buffer
 constexpr int PVOX = PW * PW;          // 289
 constexpr int NT_ = 768;               // threads: 12 waves
 constexpr int NX = (PVOX * 8 + NT_ - 1) / NT_;  // 4 pieces per thread
-constexpr int FMOFF = 8 * RP;          // tile group 1 = tile rows 4..7 = patch rows +8
 constexpr int MAXPH = 4;
 
 struct Phase {

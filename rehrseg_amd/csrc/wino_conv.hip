@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
 // the MFMAs of the current one; one barrier per item, placed where nothing is pending.
 // (Rounds 1-2 ran this tile as 4 waves, one per SIMD with 16 accumulator tiles each; the 8-wave
 // organisation below replaced it: -1.5 ms per cfg-2 step, profiles/r03_ab_superseded.txt.)
-constexpr int PW2 = 18, PVOX2 = 18 * 18, NX2 = (PVOX2 * 8 + 255) / 256;  // 11 pieces per thread
+constexpr int PW2 = 18, PVOX2 = 18 * 18;
 // LDS patch layout of the big-tile kernel: within a row the 9 even columns come first, then the 9 odd
 // ones, and rows are padded by 8 floats.  A fragment read touches, per 16-lane phase, tiles (th 0..1,
 // tw 0..7) at ONE column parity: neighbouring tiles are then 36 floats (9 bank groups, odd) apart and
@@ -301,7 +301,6 @@ constexpr int PW2 = 18, PVOX2 = 18 * 18, NX2 = (PVOX2 * 8 + 255) / 256;  // 11 p
 // both strides even: SQ_LDS_BANK_CONFLICT was 68 % of SQ_LDS_IDX_ACTIVE.
 constexpr int RP2 = PW2 * LDX + 8;     // row pitch in floats
 constexpr int BUF2 = PW2 * RP2;        // floats per slice buffer
-constexpr int FMOFF = 8 * RP2;         // tile group 1 = tile rows 4..7 = patch rows +8
 
 // U2 in MFMA fragment order: [jd][xi][Npad/32][kchunks][kk][lane 64][4]; lane = half*32 + col
 // holds n = nt*32 + col, ci = chunk*32 + kk*8 + half*4 + e (zero beyond Cin)

@@ -158,6 +158,7 @@ USE_WINOGRAD_WGRAD = True   # False -> REHR_DBG_WGRAD_DIRECT
 USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps (False -> REHR_DBG_GG_NO_HALO)
 USE_WGRAD_TAP_SKIP = True   # Winograd weight gradient: a depth tap walks only the slices whose source slice exists
 W32P_BLOCKS = 0   # 0: the library picks; 1 / 2 force two 256-thread blocks per CU / one 512-thread block (tests, A/B)
+PHASE_INTERLEAVE = True   # multi-phase launches: the phases of a lattice tile as consecutive blocks of one XCD
 USE_WINO_FLAT8 = True   # fp32 Winograd on planes that 16 x 16 regions tile badly: wino_flat8_conv_kernel
 WINO_FLAT8_TILES = 0    # 0: the library picks 32 or 64 tiles per block; 1 / 2 force 32 / 64 (tests, A/B)
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
@@ -197,7 +198,7 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
         if bias is not None and bias.dtype != torch.float32:
             raise L.RehrsegHipError("bias stays float32")
         d.flags = L.GG_Y_F32 if y.dtype == torch.float32 else 0
-        d.debug_flags = 0 if USE_HALO_BF16 else L.DBG_GG_NO_HALO
+        d.debug_flags = (0 if USE_HALO_BF16 else L.DBG_GG_NO_HALO)
     elif wp.dtype != torch.float32 or y.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
         raise L.RehrsegHipError("fp32 gather-GEMM: every operand must be float32")
     elif USE_WINOGRAD and tile[0] >= 0:
@@ -210,6 +211,8 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             global wino_launches
             wino_launches += 1
             d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
+    if not PHASE_INTERLEAVE:
+        d.debug_flags |= L.DBG_GG_NO_INTERLEAVE
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
@@ -352,6 +355,12 @@ def im2col(x, w, out_dims, stride, pad, Kpad):
     d.Cout, d.ldy = w.shape[0], Kpad
     L.check(L.load().rehr_im2col_f32(C.byref(d), _ptr(col), Kpad, _stream()), "rehr_im2col_f32")
     return col
+
+
+def small_cin_wgrad_on_mfma(x, w, dy, stride, pad):
+    """True when the thin-input weight gradient has its own matrix-core kernel for this shape (no im2col route)."""
+    d = _direct_desc(x, w.contiguous(), None, dy, stride, pad, 0, 0.0, None, 0)
+    return bool(L.load().rehr_conv_small_cin_wgrad_on_mfma(C.byref(d)))
 
 
 def small_cin_wgrad(x, w, dy, stride, pad, want_bias):

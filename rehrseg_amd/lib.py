@@ -27,6 +27,7 @@ DBG_GG_FLAT8_HALF = 4
 DBG_GG_FLAT8_FULL = 8
 DBG_GG_W32P_TWO_PER_CU = 16
 DBG_GG_W32P_ONE_PER_CU = 32
+DBG_GG_NO_INTERLEAVE = 64
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p
@@ -120,6 +121,7 @@ PROTOTYPES = {
     "rehr_conv_small_cin_fwd_f32": (C.c_int, [_P_DC, _vp]),
     "rehr_im2col_f32": (C.c_int, [_P_DC, _vp, _i32, _vp]),
     "rehr_conv_small_cin_wgrad_workspace_bytes": (_i64, [_P_DC]),
+    "rehr_conv_small_cin_wgrad_on_mfma": (C.c_int, [_P_DC]),
     "rehr_conv_small_cin_wgrad_f32": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),
     "rehr_conv_small_cout_fwd_f32": (C.c_int, [_P_DC, _vp]),
     "rehr_conv_small_cout_dgrad_f32": (C.c_int, [_P_DC, _vp, _vp]),

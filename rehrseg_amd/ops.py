@@ -437,8 +437,9 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
     if Cin <= 2:
         # thin input: im2col columns (k = ci*T + tap) + a 1x1x1 weight gradient on the MFMA path
         Cout, kcols = w.shape[0], Cin * T
-        if Cout % 32:
-            return be.small_cin_wgrad(x1, w, dz, cfg.stride, cfg.pad, want_bias)
+        if Cout % 32 or (hasattr(be, "small_cin_wgrad_on_mfma") and
+                         be.small_cin_wgrad_on_mfma(x1, w, dz, cfg.stride, cfg.pad)):
+            return be.small_cin_wgrad(x1, w, dz, cfg.stride, cfg.pad, want_bias)   # dY and x read once each
         kpad = -(-kcols // 32) * 32
         col = be.im2col(x1, w, _spatial(dz), cfg.stride, cfg.pad, kpad)
         tmp = torch.empty((Cout, kpad), dtype=w.dtype, device=w.device)

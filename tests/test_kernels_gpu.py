@@ -451,6 +451,34 @@ def test_thin_input_conv(Cin, Cout, K, stride, pad):
          lambda x, w, b: torch.relu(F.conv3d(x, w, b, stride, pad)), [x, w, b], [False, True, True])
 
 
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dims", [(1, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 6, 37, 150)),    # 3 column tiles, row tail
+                                                         (2, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 3, 9, 70)),
+                                                         (1, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 12, 65)),
+                                                         (1, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 2, 8, 33)),
+                                                         (1, 32, (3, 7, 7), (1, 2, 2), (1, 3, 3), (1, 4, 20, 140)),
+                                                         (2, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), (1, 9, 64, 130))])
+def test_thin_input_weight_gradient_kernel(Cin, Cout, K, stride, pad, dims):
+    """thin_cin_wgrad_kernel (dY and x read once, voxel-reduction on v_mfma_f32_16x16x4_f32, bias column) against
+    fp64 autograd: several tiles per block, column tiles, ragged rows / columns, both input-channel counts, every
+    instantiated (C_out, tap-tile) shape; bitwise reproducible (slabs summed in a fixed order)."""
+    from rehrseg_amd import hip_backend as hb
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=124).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = (_mk(Cout, Cin, *K, seed=125) / (Cin * K[0] * K[1] * K[2]) ** 0.5).to(_dev())
+    cfg = ops.ConvCfg(stride, pad, False)
+    od = tuple((i + 2 * p - k) // s + 1 for i, k, s, p in zip((D, H, W), K, stride, pad))
+    dy = _mk(N, Cout, *od, seed=126).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    assert hb.small_cin_wgrad_on_mfma(x, w, dy, stride, pad)
+    dw, db = ops.conv_wgrad(dy, x, None, w, cfg, True)
+    dw2, db2 = ops.conv_wgrad(dy, x, None, w, cfg, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    xr, wr = x.double().cpu(), w.double().cpu().requires_grad_()
+    br = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    rw, rb = torch.autograd.grad(F.conv3d(xr, wr, br, stride, pad), [wr, br], dy.double().cpu())
+    _close(dw, rw, 2e-5)
+    _close(db, rb, 2e-5)
+
+
 def test_thin_input_conv_instnorm():
     x = _mk(2, 1, 6, 12, 13, seed=27)
     w = _mk(32, 1, 3, 3, 3, seed=28) / 5.0
@@ -666,3 +694,39 @@ def test_uasr_mix(K, D, N, hw):
     ref = torch.autograd.grad([ro, ru], rin, [g0.double(), g1.double()])
     for a, e in zip(got, ref):
         _close(a.reshape(e.shape), e, 1e-5)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("Cin,Cout,stride,dims", [(64, 32, (2, 2, 2), (2, 5, 12, 20)),      # 19 lattice tiles: padding blocks
+                                                   (320, 256, (2, 2, 2), (1, 4, 4, 4)),      # several N tiles, one M tile
+                                                   (128, 64, (1, 2, 2), (1, 6, 16, 16))])
+def test_phase_interleaved_grid_is_bit_identical(Cin, Cout, stride, dims, mixed, monkeypatch):
+    """Kernel = stride transposed convolution (nnU-Net UNetDecoder.transpconvs): the phases of a lattice tile as
+    consecutive blocks of one XCD (default) against blockIdx.z = phase (REHR_DBG_GG_NO_INTERLEAVE) -- the same blocks
+    doing the same arithmetic in another order: identical bits, forward and the strided-conv input gradient alike; and
+    against fp64."""
+    from rehrseg_amd import hip_backend as hb
+    N, D, H, W = dims
+    dt = torch.bfloat16 if mixed else torch.float32
+    x = _mk(N, Cin, D, H, W, seed=201).to(_dev()).to(dt).contiguous(memory_format=torch.channels_last_3d)
+    w = (_mk(Cin, Cout, *stride, seed=202) / Cin ** 0.5).to(_dev())
+    b = _mk(Cout, seed=203).to(_dev())
+    cfg = ops.ConvCfg(stride, (0, 0, 0), True)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(hb, "PHASE_INTERLEAVE", flag)
+        out[flag] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_NONE, 0.0, 0)[0]
+    assert torch.equal(out[True], out[False])
+    wq = w.to(dt).double().cpu() if mixed else w.double().cpu()
+    ref = F.conv_transpose3d(x.double().cpu(), wq, b.double().cpu(), stride)
+    _close(out[True].float(), ref, 1e-2 if mixed else TOL)
+    # the input gradient of the matching strided convolution walks the same phases
+    w2 = (_mk(Cout, Cin, 3, 3, 3, seed=204) / (27 * Cin) ** 0.5).to(_dev())
+    cfg2 = ops.ConvCfg(stride, (1, 1, 1), False)
+    od = tuple((i + 2 - 3) // s + 1 for i, s in zip((D, H, W), stride))
+    dz = _mk(N, Cout, *od, seed=205).to(_dev()).to(dt).contiguous(memory_format=torch.channels_last_3d)
+    g = {}
+    for flag in (True, False):
+        monkeypatch.setattr(hb, "PHASE_INTERLEAVE", flag)
+        g[flag] = ops.conv_dgrad(dz, w2, (D, H, W), Cin, 0, cfg2)[0]
+    assert torch.equal(g[True], g[False])
