@@ -158,6 +158,14 @@ int rehr_sum_slabs_stats_f32(const float* slabs, int32_t S, int64_t slab_stride,
                              float* y, int32_t N, int64_t SV, int32_t C, int32_t act, float slope,
                              double* stats, void* stream);
 
+/* Mixed precision: the same two combines with fp32 slabs (the bf16 gather-GEMM writes them with REHR_GG_Y_F32) and a
+ * bf16 result; statistics are formed from the fp32 sums, like the conv epilogues.                  */
+int rehr_sum_slabs_bias_act_bf16(const float* slabs, int32_t S, int64_t slab_stride, const float* bias, void* y,
+                                 int64_t rows, int32_t C, int32_t act, float slope, void* stream);
+int rehr_sum_slabs_stats_bf16(const float* slabs, int32_t S, int64_t slab_stride, const float* bias, void* y,
+                              int32_t N, int64_t SV, int32_t C, int32_t act, float slope, double* stats,
+                              void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Weight gradient (Conv3d.weight.grad / ConvTranspose3d.weight.grad):
  *

@@ -829,8 +829,20 @@ extern "C" int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_
 // y[row][c] = act(bias[c] + sum_s slabs[s][row][c])   (few-tile, many-tap contractions
 // such as feature_fuse run as S partial launches over tap ranges; fixed summation order)
 namespace {
+// TO = float or __bf16: the combined value is stored in the activations' dtype (mixed precision: fp32 slabs from the
+// bf16 gather-GEMM with REHR_GG_Y_F32, bf16 activations out)
+__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(__bf16* p, const f32x4& v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  bf4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+  *reinterpret_cast<bf4*>(p) = o;
+}
+
+template <typename TO>
 __global__ void sum_slabs_bias_act_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,
-                                          const float* __restrict__ bias, float* __restrict__ y, int64_t rows,
+                                          const float* __restrict__ bias, TO* __restrict__ y, int64_t rows,
                                           int C, int act, float slope) {
   const int c4n = C >> 2;
   const int64_t total = rows * c4n;
@@ -842,7 +854,7 @@ __global__ void sum_slabs_bias_act_kernel(const float* __restrict__ slabs, int S
     for (int s = 0; s < S; ++s) v += reinterpret_cast<const f32x4*>(slabs + s * slab_stride)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
-    reinterpret_cast<f32x4*>(y)[i] = v;
+    store4(y + 4 * i, v);
   }
 }
 }  // namespace
@@ -850,8 +862,9 @@ __global__ void sum_slabs_bias_act_kernel(const float* __restrict__ slabs, int S
 namespace {
 // the same combine for one sample per blockIdx.y, with the per-(n,c) sum / sum of squares of the
 // stored value (SE pool / InstanceNorm statistics of a split-K layer)
+template <typename TO>
 __global__ void sum_slabs_stats_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,
-                                       const float* __restrict__ bias, float* __restrict__ y, int64_t SV, int C,
+                                       const float* __restrict__ bias, TO* __restrict__ y, int64_t SV, int C,
                                        int64_t rows_per_block, int act, float slope, double* __restrict__ stats) {
   const int n = blockIdx.y;
   const int64_t s_begin = (int64_t)blockIdx.x * rows_per_block;
@@ -870,7 +883,7 @@ __global__ void sum_slabs_stats_kernel(const float* __restrict__ slabs, int S, i
                        acc[0][e] += v[e];
                        acc[1][e] += (double)v[e] * v[e];
                      }
-                     *reinterpret_cast<f32x4*>(y + row * C + c) = v;
+                     store4(y + row * C + c, v);   // (statistics: of the fp32 sums, as the conv epilogues form them)
                    });
 }
 }  // namespace
@@ -884,8 +897,33 @@ extern "C" int rehr_sum_slabs_stats_f32(const float* slabs, int32_t S, int64_t s
   if ((((uintptr_t)slabs) | ((uintptr_t)y)) & 15) return REHR_EINVAL;
   const int64_t rpb = rows_per_block_for(SV, C, N);
   const int blocks = (int)((SV + rpb - 1) / rpb);
-  hipLaunchKernelGGL(sum_slabs_stats_kernel, dim3(blocks, N), dim3(EW_THREADS), 0, (hipStream_t)stream, slabs, S,
+  hipLaunchKernelGGL(sum_slabs_stats_kernel<float>, dim3(blocks, N), dim3(EW_THREADS), 0, (hipStream_t)stream, slabs, S,
                      slab_stride, bias, y, SV, C, rpb, act, slope, stats);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_sum_slabs_stats_bf16(const float* slabs, int32_t S, int64_t slab_stride, const float* bias,
+                                         void* y, int32_t N, int64_t SV, int32_t C, int32_t act, float slope,
+                                         double* stats, void* stream) {
+  if (!slabs || !y || !stats || S < 1 || N < 1 || N > 65535 || SV < 1 || C < 4 || C % 4 || C > 1024 ||
+      slab_stride < (int64_t)N * SV * C || slab_stride % 4)
+    return REHR_EINVAL;
+  if ((((uintptr_t)slabs) & 15) || (((uintptr_t)y) & 7)) return REHR_EINVAL;
+  const int64_t rpb = rows_per_block_for(SV, C, N);
+  const int blocks = (int)((SV + rpb - 1) / rpb);
+  hipLaunchKernelGGL(sum_slabs_stats_kernel<__bf16>, dim3(blocks, N), dim3(EW_THREADS), 0, (hipStream_t)stream, slabs, S,
+                     slab_stride, bias, (__bf16*)y, SV, C, rpb, act, slope, stats);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_sum_slabs_bias_act_bf16(const float* slabs, int32_t S, int64_t slab_stride, const float* bias,
+                                            void* y, int64_t rows, int32_t C, int32_t act, float slope, void* stream) {
+  if (!slabs || !y || S < 1 || rows < 1 || C < 4 || C % 4 || slab_stride < rows * C || slab_stride % 4) return REHR_EINVAL;
+  if ((((uintptr_t)slabs) & 15) || (((uintptr_t)y) & 7)) return REHR_EINVAL;
+  hipLaunchKernelGGL(sum_slabs_bias_act_kernel<__bf16>, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, slabs, S, slab_stride, bias, (__bf16*)y, rows, C, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -895,7 +933,7 @@ extern "C" int rehr_sum_slabs_bias_act_f32(const float* slabs, int32_t S, int64_
                                            void* stream) {
   if (!slabs || !y || S < 1 || rows < 1 || C < 4 || C % 4 || slab_stride < rows * C || slab_stride % 4) return REHR_EINVAL;
   if ((((uintptr_t)slabs) | ((uintptr_t)y)) & 15) return REHR_EINVAL;
-  hipLaunchKernelGGL(sum_slabs_bias_act_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0,
+  hipLaunchKernelGGL(sum_slabs_bias_act_kernel<float>, dim3(ew_blocks(rows * (C / 4))), dim3(EW_THREADS), 0,
                      (hipStream_t)stream, slabs, S, slab_stride, bias, y, rows, C, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;

@@ -477,7 +477,10 @@ extern "C" int rehr_gather_gemm_multi_bf16(const rehr_gather_gemm_desc* descs, i
     if (descs[i].Npad != descs[0].Npad || descs[i].N != descs[0].N || descs[i].wp != descs[0].wp ||
         descs[i].x1 != descs[0].x1 || descs[i].Cin != descs[0].Cin || descs[i].c1 != descs[0].c1)
       return REHR_EINVAL;
-    if (!(descs[i].debug_flags & REHR_DBG_GG_NO_HALO)) {   // unit-stride 3x3(x3) taps: input brick + halo staged in LDS
+    // (tap-range parts of a split-K launch -- they differ in y -- stay together in ONE generic grid: a halo launch per
+    // part would run them one after the other on a few CUs each)
+    const bool split_part = count > 1 && descs[i].y != descs[(i + 1) % count].y;
+    if (!(descs[i].debug_flags & REHR_DBG_GG_NO_HALO) && !split_part) {   // unit-stride 3x3(x3) taps: input brick + halo staged in LDS
       rc = halo_conv_bf16_try(descs[i], (hipStream_t)stream);
       if (rc == REHR_OK) continue;
       if (rc != REHR_ENOSUP) return rc;

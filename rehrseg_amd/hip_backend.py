@@ -259,20 +259,26 @@ def gather_gemm_multi(calls):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
 
 
-def sum_slabs_bias_act(slabs, S, bias, act, slope, stats=None):
-    """slabs: (S*N, C, D, H, W) NDHWC partial results -> (N, C, D, H, W) = act(bias + sum over S);
-    `stats` (N, C, 2) double, pre-zeroed: also accumulate the per-(n,c) sum / sum of squares."""
+def sum_slabs_bias_act(slabs, S, bias, act, slope, stats=None, out_dtype=None):
+    """slabs: (S*N, C, D, H, W) NDHWC fp32 partial results -> (N, C, D, H, W) = act(bias + sum over S) in `out_dtype`
+    (fp32, or bf16 on the mixed-precision path); `stats` (N, C, 2) double, pre-zeroed: also accumulate the per-(n,c)
+    sum / sum of squares (of the fp32 sums)."""
     _chk_dev(slabs, bias, f64=(stats,))
+    if slabs.dtype != torch.float32:
+        raise L.RehrsegHipError("split-K slabs are float32")
     SN, Cc, D, H, W = slabs.shape
     N = SN // S
-    y = new_act(N, Cc, D, H, W, like=slabs)
+    bf = out_dtype == torch.bfloat16
+    y = new_act(N, Cc, D, H, W, like=slabs, dtype=torch.bfloat16 if bf else torch.float32)
     rows = N * D * H * W
+    lib = L.load()
     if stats is not None:
-        L.check(L.load().rehr_sum_slabs_stats_f32(_ptr(slabs), S, rows * Cc, _ptr(bias), _ptr(y), N, D * H * W, Cc, act,
-                                                  slope, _ptr(stats), _stream()), "rehr_sum_slabs_stats_f32")
+        fn = lib.rehr_sum_slabs_stats_bf16 if bf else lib.rehr_sum_slabs_stats_f32
+        L.check(fn(_ptr(slabs), S, rows * Cc, _ptr(bias), _ptr(y), N, D * H * W, Cc, act, slope, _ptr(stats), _stream()),
+                "rehr_sum_slabs_stats")
         return y
-    L.check(L.load().rehr_sum_slabs_bias_act_f32(_ptr(slabs), S, rows * Cc, _ptr(bias), _ptr(y), rows, Cc, act, slope,
-                                                 _stream()), "rehr_sum_slabs_bias_act_f32")
+    fn = lib.rehr_sum_slabs_bias_act_bf16 if bf else lib.rehr_sum_slabs_bias_act_f32
+    L.check(fn(_ptr(slabs), S, rows * Cc, _ptr(bias), _ptr(y), rows, Cc, act, slope, _stream()), "rehr_sum_slabs_bias_act")
     return y
 
 

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "rehr_pack_weights_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "rehr_sum_slabs_bias_act_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "rehr_sum_slabs_stats_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "rehr_sum_slabs_bias_act_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "rehr_sum_slabs_stats_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp]),
     "rehr_wgrad_workspace_bytes": (_i64, [_P_WG]),
     "rehr_wgrad_uses_winograd": (C.c_int, [_P_WG]),
     "rehr_wgrad_f32": (C.c_int, [_P_WG, _vp]),

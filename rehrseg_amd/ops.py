@@ -231,15 +231,17 @@ def _sub_taps(t, a, b):
     return (b - a, off0 + offs * a, offs, k0 + ks * a, ks)
 
 
-def _tap_split(lattice, N, Npad, taps, Cin):
+def _tap_split(lattice, N, Npad, taps, Cin, bf16=False):
     """Tap ranges (<= 8) for a split-K launch, or None when the plain launch already fills the chip.
-    Depth taps are split first (single taps or ranges), then the row taps in two."""
+    Depth taps are split first (single taps or ranges), then the row taps in two.
+    bf16: no Winograd kernels to leave lattices to (the LDS halo-brick kernel declines these few-tile lattices or would
+    run them on a handful of CUs: the split gather launch fills the chip)."""
     vox = lattice[0] * lattice[1] * lattice[2]
     blocks = -(-vox // 128) * (Npad // (128 if Npad % 128 == 0 else (64 if Npad % 64 == 0 else 32))) * N
     T = taps[0][0] * taps[1][0] * taps[2][0]
     if blocks > 160 or T * Cin < 2048 or taps[0][0] * taps[1][0] < 2:
         return None
-    if taps[0][0] <= 3 and taps[1][0] == 3 and taps[2][0] == 3 and taps[1][2] in (1, -1) and taps[2][2] in (1, -1):
+    if not bf16 and taps[0][0] <= 3 and taps[1][0] == 3 and taps[2][0] == 3 and taps[1][2] in (1, -1) and taps[2][2] in (1, -1):
         # unit-stride 3x3 taps: leave lattices the Winograd kernels accept (8x16-output regions, <= 1.3x
         # padding; librehrseg's wino_workspace_bytes applies the same rule) to them
         Lh, Lw = lattice[1], lattice[2]
@@ -312,17 +314,18 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     # Few lattice tiles but a long K (feature_fuse: 128 tiles x 1152 taps; nnU-Net stages at <= 8^3 voxels:
     # 40 tiles x 27 taps x 320 channels): split the taps over S partial launches in one grid and combine the
     # slabs in a fixed order (the combine carries bias, activation and the statistics epilogue).
-    bf16 = x1.dtype == torch.bfloat16   # (the split-K combine kernels are fp32; bf16 layers run unsplit)
+    bf16 = x1.dtype == torch.bfloat16   # (mixed precision: fp32 slabs from the bf16 kernels, bf16 out of the combine)
     # (strided convolutions too: nnU-Net's 8^3 -> 4^3 stage is 10 blocks walking 8640 products each without it)
-    parts = _tap_split(out_dims, N, Npad, taps, Cin) if not bf16 else None
+    parts = _tap_split(out_dims, N, Npad, taps, Cin, bf16)
     if parts is not None and Cout % 4 == 0:
         S = len(parts)
-        slabs = be.new_act(S * N, Cout, *out_dims, like=x1)
+        slabs = be.new_act(S * N, Cout, *out_dims, like=x1, **({"dtype": torch.float32} if bf16 else {}))
         calls = [(x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), tp, K[1], K[2],
                   wp, Npad, slabs[s_i * N:(s_i + 1) * N], out_dims, Cout, (1, 1, 1), (0, 0, 0), None,
                   ACT_NONE, 0.0, None, 0, choose_tile(tuple(out_dims))) for s_i, tp in enumerate(parts)]
         be.gather_gemm_multi(calls)
-        return be.sum_slabs_bias_act(slabs, S, bias, act, slope, stats if stats_mode else None), stats
+        okw = {"out_dtype": torch.bfloat16} if bf16 else {}
+        return be.sum_slabs_bias_act(slabs, S, bias, act, slope, stats if stats_mode else None, **okw), stats
     y = be.new_act(N, Cout, *out_dims, like=x1)
     be.gather_gemm(x1, x2, c1, in_dims, Cin, out_dims, cfg.stride, tuple(-p for p in cfg.pad), taps, K[1], K[2],
                    wp, Npad, y, out_dims, Cout, (1, 1, 1), (0, 0, 0), bias, act, slope, stats, stats_mode,
@@ -360,18 +363,20 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True, x_d
         else:
             wpart = w if (lo == 0 and cnt == w.shape[1]) else w[:, lo:lo + cnt].contiguous()
             wp, Npad = _pack(wpart, 1, dz.dtype)
-            if cfg.stride == (1, 1, 1) and cnt % 4 == 0 and dz.dtype != torch.bfloat16:
+            if cfg.stride == (1, 1, 1) and cnt % 4 == 0:
                 # low-resolution stages: split the taps like the forward does (one phase, no epilogue)
                 taps = [phase_taps(K[a], 1, cfg.pad[a], 0) for a in range(3)]
-                parts = _tap_split(in_dims, N, Npad, taps, Cz) if all(t is not None for t in taps) else None
+                zbf = dz.dtype == torch.bfloat16
+                parts = _tap_split(in_dims, N, Npad, taps, Cz, zbf) if all(t is not None for t in taps) else None
                 if parts is not None:
                     S = len(parts)
-                    slabs = be.new_act(S * N, cnt, *in_dims, like=dz)
+                    slabs = be.new_act(S * N, cnt, *in_dims, like=dz, **({"dtype": torch.float32} if zbf else {}))
                     be.gather_gemm_multi([(dz, None, Cz, _spatial(dz), Cz, tuple(in_dims), (1, 1, 1), (0, 0, 0), tp, K[1],
                                            K[2], wp, Npad, slabs[s_i * N:(s_i + 1) * N], tuple(in_dims), cnt, (1, 1, 1),
                                            (0, 0, 0), None, ACT_NONE, 0.0, None, 0, choose_tile(tuple(in_dims)))
                                           for s_i, tp in enumerate(parts)])
-                    out.append(be.sum_slabs_bias_act(slabs, S, None, ACT_NONE, 0.0))
+                    out.append(be.sum_slabs_bias_act(slabs, S, None, ACT_NONE, 0.0,
+                                                     **({"out_dtype": torch.bfloat16} if zbf else {})))
                     continue
             dx = be.new_act(N, cnt, *in_dims, like=dz, zero=_has_empty_phase(K, cfg.stride, cfg.pad))
             _phased_gather(dz, None, Cz, Cz, wp, Npad, dx, cnt, K, cfg.stride, cfg.pad, None, ACT_NONE, 0.0, None, 0)
