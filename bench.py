@@ -435,16 +435,20 @@ def main():
         if dominant:
             r = fams[dominant]
             r["kernel"] = names.get(dominant, dominant)
-            # HBM bytes per launch from the committed PMC passes of the same command (tools/pmc_traffic.py; rocprofv3
-            # counters cannot be collected from inside the timed run)
-            # (profiles/r02_pmc_hbm_flavr.json: tools/pmc_hbm.py over three rocprofv3 passes of `bench.py --workload flavr`)
-            tp = os.path.join(ROOT, "profiles", "r02_pmc_hbm_flavr.json")
-            if args.workload == "flavr" and size == 128 and dominant == "wino_conv" and os.path.exists(tp):
-                ks = json.load(open(tp)).get("kernels", {})
-                k = ks.get("wino_conv_big8_kernel") or {}
-                if k.get("hbm_bytes_per_launch"):
-                    r["traffic"] = k["hbm_bytes_per_launch"]
-                    r["traffic_source"] = "profiles/r02_pmc_hbm_flavr.json (PMC FETCH_SIZE x2 + WRITE_SIZE per launch)"
+            # HBM bytes per launch from the committed PMC passes of the same command (rocprofv3 counters cannot be
+            # collected from inside the timed run): tools/pmc_hbm.py over three rocprofv3 passes of
+            # `bench.py --workload flavr` (tools/collect_profiles_r03.sh pmc), newest round first
+            if args.workload == "flavr" and size == 128 and dominant == "wino_conv":
+                for tag in ("r03", "r02"):
+                    tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_flavr.json")
+                    if not os.path.exists(tp):
+                        continue
+                    k = json.load(open(tp)).get("kernels", {}).get("wino_conv_big8_kernel") or {}
+                    if k.get("hbm_bytes_per_launch"):
+                        r["traffic"] = k["hbm_bytes_per_launch"]
+                        r["traffic_source"] = (f"profiles/{tag}_pmc_hbm_flavr.json (PMC FETCH_SIZE x2 + WRITE_SIZE per launch "
+                                               "of wino_conv_big8_kernel; separate rocprofv3 passes of this command)")
+                        break
             rec["roofline"] = r
         for n, r in fams.items():
             if r and n != dominant:

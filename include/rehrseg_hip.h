@@ -258,6 +258,13 @@ int64_t rehr_conv_small_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc* d
 /* 1 when rehr_conv_small_cin_wgrad_f32 takes this shape on the matrix cores (thin_cin_conv.hip: C_out 32 / 64,
  * 1x3x3 / 3x3x3 / (3,7,7) taps, stride_w <= 2) -- dY and x are then each read once, no im2col columns */
 int rehr_conv_small_cin_wgrad_on_mfma(const rehr_direct_conv_desc* d);
+/* Mixed precision: the same layers with y (forward) / dY (weight gradient) pointing at bf16 elements -- the thin-input
+ * layers compute in fp32 on the fp32 image, the layer behind takes bf16.  Matrix-core shapes only
+ * (rehr_conv_small_cin_wgrad_on_mfma; C_out 32 / 64, kW <= 8, stride_w <= 2 for the forward), else REHR_ENOSUP.
+ * Same workspace query as the fp32 entry. */
+int rehr_conv_small_cin_fwd_ybf16(const rehr_direct_conv_desc* d, void* stream);
+int rehr_conv_small_cin_wgrad_dybf16(const rehr_direct_conv_desc* d, float* dw, float* dbias, float* workspace,
+                                     int64_t workspace_bytes, void* stream);
 /* dw (Cout,Cin,KD,KH,KW) = sum_{n,o} dY[n,o,co] * x[n,o*s-p+k,ci]; dbias optional */
 int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* d, float* dw,
                                   float* dbias, float* workspace,
@@ -405,6 +412,11 @@ int rehr_window_stem_assemble_f32(const float* g0, const float* g1, const float*
                                   const float* mean, const float* bias, float* y, int32_t B,
                                   int32_t nwin, int32_t nslices, int64_t HW, int32_t C,
                                   int32_t act, float slope, void* stream);
+/* the same with a bf16 result (mixed precision: the teacher's first block takes bf16); fp32 responses in */
+int rehr_window_stem_assemble_bf16(const float* g0, const float* g1, const float* g2,
+                                   const float* mean, const float* bias, void* y, int32_t B,
+                                   int32_t nwin, int32_t nslices, int64_t HW, int32_t C,
+                                   int32_t act, float slope, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Fused segmentation loss: softmax + cross-entropy, optionally

@@ -52,6 +52,8 @@ def encoder(sd, x, prefix="encoder.", emu=None, upto=4):
     """resnet_3D.py:183-189 with unet_18's layout (:238-261): strides (1,1,1),
     (1,2,2), (1,2,2), (1,1,1); depth is never reduced."""
     x0 = torch.relu(F.conv3d(x, sd[prefix + "stem.0.weight"], sd.get(prefix + "stem.0.bias"), (1, 2, 2), (1, 3, 3)))
+    if emu is not None:
+        x0 = emu.act(x0)     # the stem computes in fp32 on the fp32 image and stores bf16 (mixed precision)
     feats = [x0]
     cur = x0
     for li, stride in ((1, (1, 1, 1)), (2, (1, 2, 2)), (3, (1, 2, 2)), (4, (1, 1, 1)))[:upto]:

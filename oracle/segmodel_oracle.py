@@ -26,13 +26,16 @@ def _t(v):
 def _cna(sd, p, x, k, stride, eps, slope, emu=None):
     k = _t(k)
     pad = tuple((i - 1) // 2 for i in k)
-    if emu is None or x.shape[1] <= 2:                                       # (thin-input layers stay fp32 on the device)
+    if emu is None:
         y = F.conv3d(x, sd[p + "conv.weight"], sd.get(p + "conv.bias"), _t(stride), pad)
         y = F.instance_norm(y, weight=sd[p + "norm.weight"], bias=sd[p + "norm.bias"], eps=eps)
         return F.leaky_relu(y, slope)
-    # mixed precision (oracle/bf16_emul.py): bf16 operands, statistics from the unrounded accumulators, the conv output
-    # and the block output stored as bf16
-    y = F.conv3d(emu.act(x), emu.weight(sd[p + "conv.weight"]), sd.get(p + "conv.bias"), _t(stride), pad)
+    # mixed precision (oracle/bf16_emul.py): bf16 operands (thin-input layers: fp32 operands, the image is fp32),
+    # statistics from the unrounded accumulators, the conv output and the block output stored as bf16
+    if x.shape[1] <= 2:
+        y = F.conv3d(x, sd[p + "conv.weight"], sd.get(p + "conv.bias"), _t(stride), pad)
+    else:
+        y = F.conv3d(emu.act(x), emu.weight(sd[p + "conv.weight"]), sd.get(p + "conv.bias"), _t(stride), pad)
     mean = y.mean(dim=(2, 3, 4), keepdim=True)
     var = y.var(dim=(2, 3, 4), unbiased=False, keepdim=True)
     g, b = sd[p + "norm.weight"].view(1, -1, 1, 1, 1), sd[p + "norm.bias"].view(1, -1, 1, 1, 1)

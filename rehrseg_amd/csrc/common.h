@@ -59,3 +59,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// 4 consecutive channels of one voxel in the activations' dtype (fp32, or bf16 on the mixed-precision path)
+__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(__bf16* p, const f32x4& v) {
+  typedef __bf16 bf4_t __attribute__((ext_vector_type(4)));
+  bf4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+  *reinterpret_cast<bf4_t*>(p) = o;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const __bf16* p) {
+  typedef __bf16 bf4_t __attribute__((ext_vector_type(4)));
+  const bf4_t o = *reinterpret_cast<const bf4_t*>(p);
+  return f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+}

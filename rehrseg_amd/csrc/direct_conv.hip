@@ -213,17 +213,17 @@ int wgrad_blocks(const rehr_direct_conv_desc& d, int64_t* vpb) {
 
 }  // namespace
 
-int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream);   // thin_cin_conv.hip: fp32 matrix cores
+int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream, bool y_bf16);   // thin_cin_conv.hip: fp32 matrix cores
 int64_t thin_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc& d);
 int thin_cin_wgrad_try(const rehr_direct_conv_desc& d, float* dw, float* dbias, float* workspace, int64_t workspace_bytes,
-                       hipStream_t stream);
+                       hipStream_t stream, bool dy_bf16);
 
 extern "C" int rehr_conv_small_cin_fwd_f32(const rehr_direct_conv_desc* dp, void* stream) {
   if (!dp || !small_cin_ok(*dp)) return REHR_EINVAL;
   const rehr_direct_conv_desc& d = *dp;
   if (d.stats_mode != 0 && !d.stats) return REHR_EINVAL;
   {
-    const int rc = thin_cin_fwd_try(d, (hipStream_t)stream);   // C_out 32 / 64, kW <= 8, stride_w <= 2
+    const int rc = thin_cin_fwd_try(d, (hipStream_t)stream, false);   // C_out 32 / 64, kW <= 8, stride_w <= 2
     if (rc != REHR_ENOSUP) return rc;
   }
   const int T = d.KD * d.KH * d.KW;
@@ -259,7 +259,7 @@ extern "C" int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* dp, fl
   if (!dp || !small_cin_ok(*dp) || !dw || !workspace) return REHR_EINVAL;
   const rehr_direct_conv_desc& d = *dp;
   {
-    const int rc = thin_cin_wgrad_try(d, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);   // matrix cores
+    const int rc = thin_cin_wgrad_try(d, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream, false);   // matrix cores
     if (rc != REHR_ENOSUP) return rc;
   }
   const int T = d.KD * d.KH * d.KW;
@@ -279,6 +279,20 @@ extern "C" int rehr_conv_small_cin_wgrad_f32(const rehr_direct_conv_desc* dp, fl
                      st, workspace, blocks, d.Cin, T, d.Cout, dw, dbias);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
+}
+
+// Mixed precision (BASELINE configs[4]): the thin-input layers compute in fp32 (their input is the fp32 image) but the
+// layer behind takes bf16 activations and hands back bf16 gradients -- y / dY of the descriptor point at bf16 elements
+// (ldy in elements), so no separate cast pass runs over the largest activation of the network.  Matrix-core shapes only.
+extern "C" int rehr_conv_small_cin_fwd_ybf16(const rehr_direct_conv_desc* dp, void* stream) {
+  if (!dp || !dp->x || !dp->w || !dp->y) return REHR_EINVAL;
+  if (dp->stats_mode != 0 && !dp->stats) return REHR_EINVAL;
+  return thin_cin_fwd_try(*dp, (hipStream_t)stream, true);
+}
+extern "C" int rehr_conv_small_cin_wgrad_dybf16(const rehr_direct_conv_desc* dp, float* dw, float* dbias,
+                                                float* workspace, int64_t workspace_bytes, void* stream) {
+  if (!dp || !dp->x || !dp->w || !dp->y || !dw || !workspace) return REHR_EINVAL;
+  return thin_cin_wgrad_try(*dp, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream, true);
 }
 
 extern "C" int rehr_conv_small_cin_wgrad_on_mfma(const rehr_direct_conv_desc* dp) {

@@ -8,6 +8,7 @@
 // over a block's rows in registers + LDS, and finish with one double atomic per
 // channel per block.
 #include "common.h"
+#include "pack_weights.h"
 
 namespace {
 
@@ -359,9 +360,10 @@ __global__ __launch_bounds__(256) void upmix_depth_bwd_kernel(const TY* __restri
 // constant 1 in channel 0 -- and this kernel assembles window w, slice k:
 //   y[w][k][hw][c] = relu(bias[c] + sum_{kd: 0 <= k+kd-1 <= 3} (g[kd][w+k+kd-1][hw][c] - mean[w] * r[kd][hw][c]))
 // 4x fewer multiplications than convolving every window.  nslices = slices per sample incl. the padding (= nwin + 3).
+template <typename TO>   // float, or __bf16 when the teacher runs in mixed precision (its next layer takes bf16)
 __global__ void window_stem_assemble_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
                                             const float* __restrict__ g2, const float* __restrict__ mean,
-                                            const float* __restrict__ bias, float* __restrict__ y, int B, int nwin,
+                                            const float* __restrict__ bias, TO* __restrict__ y, int B, int nwin,
                                             int nslices, int64_t HW, int C, int act, float slope) {
   const int cq = C / 4;
   const int64_t plane = HW * cq;
@@ -389,7 +391,7 @@ __global__ void window_stem_assemble_kernel(const float* __restrict__ g0, const 
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] = apply_act(s[e], act, slope);
-    reinterpret_cast<f32x4*>(y)[i] = s;
+    store4(y + 4 * i, s);
   }
 }
 
@@ -605,9 +607,11 @@ extern "C" const char* rehr_last_hip_error(void) {
 extern "C" int rehr_pack_weights_f32(const float* in, float* out, int32_t A, int32_t Apad, int32_t B,
                                      int32_t T, int32_t transpose_ab, void* stream) {
   if (!in || !out || A < 1 || Apad < A || B < 1 || T < 1) return REHR_EINVAL;
-  const int64_t total = (int64_t)T * Apad * B;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, in, out, A,
-                     Apad, B, T, transpose_ab);
+  if (packw::launch<float>(in, out, A, Apad, B, T, transpose_ab, ST) != REHR_OK) {   // (grid limits: the plain kernel)
+    const int64_t total = (int64_t)T * Apad * B;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, in, out, A,
+                       Apad, B, T, transpose_ab);
+  }
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -738,8 +742,21 @@ extern "C" int rehr_window_stem_assemble_f32(const float* g0, const float* g1, c
       !aligned16(g0) || !aligned16(g1) || !aligned16(g2) || !aligned16(y) || (bias && !aligned16(bias)))
     return REHR_EINVAL;
   const int64_t total = (int64_t)B * nwin * 4 * HW * C / 4;
-  hipLaunchKernelGGL(window_stem_assemble_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g0, g1, g2, mean,
+  hipLaunchKernelGGL(window_stem_assemble_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g0, g1, g2, mean,
                      bias, y, B, nwin, nslices, HW, C, act, slope);
+  REHR_LAUNCH_CHECK();
+  return REHR_OK;
+}
+
+extern "C" int rehr_window_stem_assemble_bf16(const float* g0, const float* g1, const float* g2, const float* mean,
+                                              const float* bias, void* y, int32_t B, int32_t nwin, int32_t nslices,
+                                              int64_t HW, int32_t C, int32_t act, float slope, void* stream) {
+  if (!g0 || !g1 || !g2 || !mean || !y || B < 1 || nwin < 1 || nslices != nwin + 3 || HW < 1 || C < 4 || C % 4 ||
+      !aligned16(g0) || !aligned16(g1) || !aligned16(g2) || (((uintptr_t)y) & 7) || (bias && !aligned16(bias)))
+    return REHR_EINVAL;
+  const int64_t total = (int64_t)B * nwin * 4 * HW * C / 4;
+  hipLaunchKernelGGL(window_stem_assemble_kernel<__bf16>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, g0, g1, g2, mean,
+                     bias, (__bf16*)y, B, nwin, nslices, HW, C, act, slope);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -830,15 +847,7 @@ extern "C" int rehr_nhwc_to_nchw_f32(const float* x, float* y, int32_t N, int32_
 // such as feature_fuse run as S partial launches over tap ranges; fixed summation order)
 namespace {
 // TO = float or __bf16: the combined value is stored in the activations' dtype (mixed precision: fp32 slabs from the
-// bf16 gather-GEMM with REHR_GG_Y_F32, bf16 activations out)
-__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-__device__ __forceinline__ void store4(__bf16* p, const f32x4& v) {
-  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-  bf4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-  *reinterpret_cast<bf4*>(p) = o;
-}
+// bf16 gather-GEMM with REHR_GG_Y_F32, bf16 activations out; store4 in common.h)
 
 template <typename TO>
 __global__ void sum_slabs_bias_act_kernel(const float* __restrict__ slabs, int S, int64_t slab_stride,

@@ -25,7 +25,7 @@ struct ThinCinParams {
   int tiles_h, tiles_w, tiles_per_img, tiles_per_block;
 };
 
-template <int NTN, int NV>   // c_out tiles (Cout = 16 NTN), voxel tiles per wave
+template <int NTN, int NV, typename TO>   // c_out tiles (Cout = 16 NTN), voxel tiles per wave, stored dtype (float / __bf16)
 __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const ThinCinParams p) {
   const rehr_direct_conv_desc& d = p.d;
   constexpr int COUT = 16 * NTN, COLS = 16 * NV, ROWS = 4;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const ThinCinParams p
     for (int i = 0; i < 4; ++i) { s1[mt][i] = 0.f; s2[mt][i] = 0.f; }
 
   const float* xn = d.x + (int64_t)n_img * d.Di * d.Hi * d.Wi * d.ldx;
-  float* yn = d.y + (int64_t)n_img * d.Do * d.Ho * d.Wo * d.ldy;
+  TO* yn = reinterpret_cast<TO*>(d.y) + (int64_t)n_img * d.Do * d.Ho * d.Wo * d.ldy;
   const int planes = d.Cin * d.KD;
   const int patch = planes * p.PH * p.PW;
   const int t_begin = blockIdx.x * p.tiles_per_block;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const ThinCinParams p
       for (int v = 0; v < NV; ++v) {
         const int ow = ow0 + v * 16 + nn;
         if (ow < d.Wo) {
-          float* yo = yn + (((int64_t)od * d.Ho + oh) * d.Wo + ow) * d.ldy + 4 * kq;
+          TO* yo = yn + (((int64_t)od * d.Ho + oh) * d.Wo + ow) * d.ldy + 4 * kq;
 #pragma unroll
           for (int mt = 0; mt < NTN; ++mt) {
             f32x4 o;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const ThinCinParams p
               s1[mt][i] += r;
               s2[mt][i] += r * r;
             }
-            *reinterpret_cast<f32x4*>(yo + mt * 16) = o;
+            store4(yo + mt * 16, o);   // (statistics above: of the fp32 values, also when the store rounds to bf16)
           }
         }
       }
@@ -168,9 +168,10 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const ThinCinParams p
 }  // namespace
 
 // rehr_conv_small_cin_fwd_f32 tries this first; REHR_ENOSUP = not a shape for it
-int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream) {
+// y_bf16: d.y points at bf16 elements (mixed precision: the layer behind takes bf16 activations)
+int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream, bool y_bf16) {
   if (d.Cin < 1 || d.Cin > 2 || (d.Cout != 32 && d.Cout != 64) || d.KW > 8 || d.sw < 1 || d.sw > 2 || d.ldy % 4 ||
-      (reinterpret_cast<uintptr_t>(d.y) & 15))
+      (reinterpret_cast<uintptr_t>(d.y) & (y_bf16 ? 7 : 15)))
     return REHR_ENOSUP;
   ThinCinParams p;
   p.d = d;
@@ -198,15 +199,17 @@ int thin_cin_fwd_try(const rehr_direct_conv_desc& d, hipStream_t stream) {
   p.tiles_per_block = (int)((tpi + bx - 1) / bx);
   bx = (tpi + p.tiles_per_block - 1) / p.tiles_per_block;
   dim3 grid((unsigned)bx, d.N);
-#define TCI_LAUNCH(NTN_, NV_)                                                                                        \
+#define TCI_LAUNCH(NTN_, NV_, TO_)                                                                                   \
   do {                                                                                                               \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cin_fwd_kernel<NTN_, NV_>),                           \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cin_fwd_kernel<NTN_, NV_, TO_>),                      \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)                   \
       return REHR_EHIP;                                                                                              \
-    hipLaunchKernelGGL((thin_cin_fwd_kernel<NTN_, NV_>), grid, dim3(256), smem, stream, p);                          \
+    hipLaunchKernelGGL((thin_cin_fwd_kernel<NTN_, NV_, TO_>), grid, dim3(256), smem, stream, p);                     \
   } while (0)
-  if (NTN == 2) TCI_LAUNCH(2, 4);
-  else TCI_LAUNCH(4, 2);
+  if (NTN == 2 && y_bf16) TCI_LAUNCH(2, 4, __bf16);
+  else if (NTN == 2) TCI_LAUNCH(2, 4, float);
+  else if (y_bf16) TCI_LAUNCH(4, 2, __bf16);
+  else TCI_LAUNCH(4, 2, float);
 #undef TCI_LAUNCH
   REHR_LAUNCH_CHECK();
   return REHR_OK;
@@ -240,7 +243,7 @@ struct ThinCinWgParams {
   float* slabs;                 // [Cin][gridDim.y * gridDim.x][COUT][NTP]
 };
 
-template <int NTM, int NTN>   // c_out tiles (Cout = 16 NTM), tap tiles
+template <int NTM, int NTN, typename TZ>   // c_out tiles (Cout = 16 NTM), tap tiles, dtype of dY (float / __bf16)
 __global__ __launch_bounds__(256, (NTM * NTN <= 8) ? 2 : 1) void thin_cin_wgrad_kernel(const ThinCinWgParams p) {
   const rehr_direct_conv_desc& d = p.d;
   constexpr int COUT = 16 * NTM, COLS = 64, ROWS = 4, NTPc = 16 * NTN;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256, (NTM * NTN <= 8) ? 2 : 1) void thin_cin_wgrad_
     for (int t = 0; t < NTN; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* xn = d.x + (int64_t)n_img * d.Di * d.Hi * d.Wi * d.ldx + ci;
-  const float* zn = d.y + (int64_t)n_img * d.Do * d.Ho * d.Wo * d.ldy;
+  const TZ* zn = reinterpret_cast<const TZ*>(d.y) + (int64_t)n_img * d.Do * d.Ho * d.Wo * d.ldy;
   const int patch = d.KD * p.PH * p.PW;
   const int t_begin = blockIdx.x * p.tiles_per_block;
   const int t_end = min(p.tiles_per_img, t_begin + p.tiles_per_block);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, (NTM * NTN <= 8) ? 2 : 1) void thin_cin_wgrad_
       const int oh = oh0 + row, ow = ow0 + col;
       f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
       if (oh < d.Ho && ow < d.Wo)
-        z = *reinterpret_cast<const f32x4*>(zn + (((int64_t)od * d.Ho + oh) * d.Wo + ow) * d.ldy + 4 * j);
+        z = load4(zn + (((int64_t)od * d.Ho + oh) * d.Wo + ow) * d.ldy + 4 * j);
       *reinterpret_cast<f32x4*>(Zs + (size_t)v * p.ZP + 4 * j) = z;
     }
     __syncthreads();
@@ -366,7 +369,7 @@ __global__ void thin_cin_wgrad_reduce_kernel(const float* __restrict__ slabs, in
 
 bool thin_cin_wgrad_plan(const rehr_direct_conv_desc& d, ThinCinWgParams& p, dim3& grid, size_t& smem) {
   if (d.Cin < 1 || d.Cin > 2 || (d.Cout != 32 && d.Cout != 64) || d.sw < 1 || d.sw > 2 || d.ldy % 4 ||
-      (reinterpret_cast<uintptr_t>(d.y) & 15))
+      (reinterpret_cast<uintptr_t>(d.y) & 7))
     return false;
   p.d = d;
   p.T = d.KD * d.KH * d.KW;
@@ -407,11 +410,12 @@ int64_t thin_cin_wgrad_workspace_bytes(const rehr_direct_conv_desc& d) {
 
 // rehr_conv_small_cin_wgrad_f32 tries this first; REHR_ENOSUP = not a shape for it
 int thin_cin_wgrad_try(const rehr_direct_conv_desc& d, float* dw, float* dbias, float* workspace, int64_t workspace_bytes,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool dy_bf16) {
   ThinCinWgParams p;
   dim3 grid;
   size_t smem;
   if (!thin_cin_wgrad_plan(d, p, grid, smem)) return REHR_ENOSUP;
+  if (!dy_bf16 && (reinterpret_cast<uintptr_t>(d.y) & 15)) return REHR_ENOSUP;
   const int64_t need = (int64_t)grid.x * grid.y * grid.z * d.Cout * p.NTP * (int64_t)sizeof(float);
   if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return REHR_EINVAL;
   p.slabs = workspace;
@@ -419,10 +423,17 @@ int thin_cin_wgrad_try(const rehr_direct_conv_desc& d, float* dw, float* dbias, 
   const int ntm = d.Cout / 16, ntn = p.NTP / 16;
 #define TCW_LAUNCH(NTM_, NTN_)                                                                                       \
   do {                                                                                                               \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cin_wgrad_kernel<NTM_, NTN_>),                        \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)                   \
-      return REHR_EHIP;                                                                                              \
-    hipLaunchKernelGGL((thin_cin_wgrad_kernel<NTM_, NTN_>), grid, dim3(256), smem, stream, p);                       \
+    if (dy_bf16) {                                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cin_wgrad_kernel<NTM_, NTN_, __bf16>),              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)                 \
+        return REHR_EHIP;                                                                                            \
+      hipLaunchKernelGGL((thin_cin_wgrad_kernel<NTM_, NTN_, __bf16>), grid, dim3(256), smem, stream, p);             \
+    } else {                                                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cin_wgrad_kernel<NTM_, NTN_, float>),               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)                 \
+        return REHR_EHIP;                                                                                            \
+      hipLaunchKernelGGL((thin_cin_wgrad_kernel<NTM_, NTN_, float>), grid, dim3(256), smem, stream, p);              \
+    }                                                                                                                \
   } while (0)
   if (ntm == 2 && ntn == 1) TCW_LAUNCH(2, 1);
   else if (ntm == 2 && ntn == 2) TCW_LAUNCH(2, 2);

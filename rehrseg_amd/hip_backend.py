@@ -346,9 +346,20 @@ def _direct_desc(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
     return d
 
 
+def small_cin_bf16_out_ok(w_shape, stride):
+    """Shapes whose thin-input forward runs on the matrix cores (thin_cin_conv.hip) and can therefore store bf16."""
+    return w_shape[1] <= 2 and w_shape[0] in (32, 64) and w_shape[4] <= 8 and stride[2] in (1, 2)
+
+
 def small_cin_fwd(x, w, bias, y, stride, pad, act, slope, stats, stats_mode):
+    """x, w, bias fp32; y fp32, or bf16 on the mixed-precision path (matrix-core shapes only)."""
     _chk_dev(x, w, bias, y, f64=(stats,))
+    if x.dtype != torch.float32:
+        raise L.RehrsegHipError("thin-input conv: the input stays float32")
     d = _direct_desc(x, w.contiguous(), bias, y, stride, pad, act, slope, stats, stats_mode)
+    if y.dtype == torch.bfloat16:
+        L.check(L.load().rehr_conv_small_cin_fwd_ybf16(C.byref(d), _stream()), "rehr_conv_small_cin_fwd_ybf16")
+        return
     L.check(L.load().rehr_conv_small_cin_fwd_f32(C.byref(d), _stream()), "rehr_conv_small_cin_fwd_f32")
 
 
@@ -370,15 +381,20 @@ def small_cin_wgrad_on_mfma(x, w, dy, stride, pad):
 
 
 def small_cin_wgrad(x, w, dy, stride, pad, want_bias):
+    """dy fp32, or bf16 (mixed precision) where the matrix-core kernel takes the shape (else cast up first)."""
     _chk_dev(x, w, dy)
-    d = _direct_desc(x, w.contiguous(), None, dy, stride, pad, 0, 0.0, None, 0)
     lib = L.load()
+    if dy.dtype == torch.bfloat16:
+        d = _direct_desc(x, w.contiguous(), None, dy, stride, pad, 0, 0.0, None, 0)
+        if not lib.rehr_conv_small_cin_wgrad_on_mfma(C.byref(d)):
+            dy = dy.float()
+    d = _direct_desc(x, w.contiguous(), None, dy, stride, pad, 0, 0.0, None, 0)
     nbytes = lib.rehr_conv_small_cin_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty_like(w, memory_format=torch.contiguous_format)
     db = torch.empty(w.shape[0], dtype=torch.float32, device=x.device) if want_bias else None
-    L.check(lib.rehr_conv_small_cin_wgrad_f32(C.byref(d), _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream()),
-            "rehr_conv_small_cin_wgrad_f32")
+    fn = lib.rehr_conv_small_cin_wgrad_dybf16 if dy.dtype == torch.bfloat16 else lib.rehr_conv_small_cin_wgrad_f32
+    L.check(fn(C.byref(d), _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream()), "rehr_conv_small_cin_wgrad")
     return dw, db
 
 
@@ -542,16 +558,20 @@ def channel_sum_actgrad(dy, y, act, slope):
     return out
 
 
-def window_stem_assemble(g, mean, bias, B, nwin, act, slope):
-    """g = three (B*(nwin+3)+1, C, 1, h, w) NDHWC per-tap responses -> y (B*nwin, C, 4, h, w) (see the header)."""
+def window_stem_assemble(g, mean, bias, B, nwin, act, slope, out_dtype=None):
+    """g = three (B*(nwin+3)+1, C, 1, h, w) NDHWC fp32 per-tap responses -> y (B*nwin, C, 4, h, w) (see the header);
+    out_dtype bf16: stored for a mixed-precision first block."""
     _chk_dev(*g, mean, bias)
     S, Cc, _, h, w = g[0].shape
     if S != B * (nwin + 3) + 1:
         raise ValueError("window_stem_assemble: slice count")
-    y = new_act(B * nwin, Cc, 4, h, w, like=g[0])
-    L.check(L.load().rehr_window_stem_assemble_f32(_ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(mean), _ptr(bias), _ptr(y),
-                                                   B, nwin, nwin + 3, h * w, Cc, act, slope, _stream()),
-            "rehr_window_stem_assemble_f32")
+    if any(t.dtype != torch.float32 for t in g):
+        raise L.RehrsegHipError("window_stem_assemble: the per-tap responses are float32")
+    bf = out_dtype == torch.bfloat16
+    y = new_act(B * nwin, Cc, 4, h, w, like=g[0], dtype=torch.bfloat16 if bf else torch.float32)
+    fn = L.load().rehr_window_stem_assemble_bf16 if bf else L.load().rehr_window_stem_assemble_f32
+    L.check(fn(_ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(mean), _ptr(bias), _ptr(y), B, nwin, nwin + 3, h * w, Cc, act,
+               slope, _stream()), "rehr_window_stem_assemble")
     return y
 
 

@@ -124,6 +124,8 @@ PROTOTYPES = {
     "rehr_im2col_f32": (C.c_int, [_P_DC, _vp, _i32, _vp]),
     "rehr_conv_small_cin_wgrad_workspace_bytes": (_i64, [_P_DC]),
     "rehr_conv_small_cin_wgrad_on_mfma": (C.c_int, [_P_DC]),
+    "rehr_conv_small_cin_fwd_ybf16": (C.c_int, [_P_DC, _vp]),
+    "rehr_conv_small_cin_wgrad_dybf16": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),
     "rehr_conv_small_cin_wgrad_f32": (C.c_int, [_P_DC, _vp, _vp, _vp, _i64, _vp]),
     "rehr_conv_small_cout_fwd_f32": (C.c_int, [_P_DC, _vp]),
     "rehr_conv_small_cout_dgrad_f32": (C.c_int, [_P_DC, _vp, _vp]),
@@ -152,6 +154,7 @@ PROTOTYPES = {
     "rehr_quad_maxpool_fwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_quad_maxpool_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rehr_window_stem_assemble_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, C.c_float, _vp]),
+    "rehr_window_stem_assemble_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, C.c_float, _vp]),
     "rehr_conv5_thin_f32_workspace_bytes": (_i64, [_P_DC]),
     "rehr_conv5_thin_f32_supported": (C.c_int, [_P_DC]),
     "rehr_conv5_thin_fwd_f32": (C.c_int, [_P_DC, _vp, _i64, _vp]),

@@ -99,10 +99,12 @@ def encoder_on_windows(enc, xpad, nwin, upto):
         one = torch.zeros((1, C, 1, H, W), dtype=xpad.dtype, device=xpad.device)
         one[:, 0] = 1.0
         inp = ops.to_cl(torch.cat([sl, one], dim=0))
-        g = [ops.fused_conv3d(inp, s.weight[:, :, kd:kd + 1].contiguous(), None, (1, 2, 2), (0, 3, 3)) for kd in range(3)]
+        g = [ops.fused_conv3d(inp, s.weight[:, :, kd:kd + 1].contiguous(), None, (1, 2, 2), (0, 3, 3), y_fp32=True)
+             for kd in range(3)]
         ssum = xpad[:, 0].sum(dim=(2, 3))                                            # (B, Dp)
         mean = (ssum[:, 0:nwin] + ssum[:, 1:nwin + 1] + ssum[:, 2:nwin + 2] + ssum[:, 3:nwin + 3]) / (4.0 * H * W)
-        x0 = ops.get_backend().window_stem_assemble(g, mean.contiguous(), s.bias, B, nwin, ops.ACT_RELU, 0.0)
+        okw = {"out_dtype": torch.bfloat16} if ops.is_mixed_precision() else {}   # layer1 takes bf16 then
+        x0 = ops.get_backend().window_stem_assemble(g, mean.contiguous(), s.bias, B, nwin, ops.ACT_RELU, 0.0, **okw)
         feats = [x0]
         for i in range(1, upto + 1):
             feats.append(getattr(enc, f"layer{i}")(feats[-1]))

@@ -159,6 +159,7 @@ class ConvCfg:
     slope: float = 0.0
     mode: str = "plain"  # plain | se | in
     eps: float = 1e-5
+    y_fp32: bool = False  # mixed precision: keep a thin-input layer's output fp32 (linear post-processing follows)
 
 
 def _spatial(x):
@@ -285,7 +286,13 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     if Cin <= 2:
         if cfg.transposed or x2 is not None:
             raise ValueError("thin-input path handles plain Conv3d only")
-        y = be.new_act(N, Cout, *out_dims, like=x1)
+        # mixed precision: fp32 arithmetic on the fp32 image, the result stored as bf16 for the layer behind (no cast
+        # pass over the network's largest activation); statistics from the fp32 accumulators
+        okw = {}
+        if (_mixed and not cfg.y_fp32 and x1.dtype == torch.float32 and hasattr(be, "small_cin_bf16_out_ok") and
+                be.small_cin_bf16_out_ok(tuple(w.shape), cfg.stride)):
+            okw["dtype"] = torch.bfloat16
+        y = be.new_act(N, Cout, *out_dims, like=x1, **okw)
         be.small_cin_fwd(x1, w, bias, y, cfg.stride, cfg.pad, act, slope, stats, stats_mode)
         return y, stats
     if _thin_out(w, cfg, x2 is not None):
@@ -445,6 +452,8 @@ def conv_wgrad(dz, x1, x2, w, cfg: ConvCfg, want_bias, out=None):
         if Cout % 32 or (hasattr(be, "small_cin_wgrad_on_mfma") and
                          be.small_cin_wgrad_on_mfma(x1, w, dz, cfg.stride, cfg.pad)):
             return be.small_cin_wgrad(x1, w, dz, cfg.stride, cfg.pad, want_bias)   # dY and x read once each
+        if dz.dtype == torch.bfloat16:
+            dz = dz.float()
         kpad = -(-kcols // 32) * 32
         col = be.im2col(x1, w, _spatial(dz), cfg.stride, cfg.pad, kpad)
         tmp = torch.empty((Cout, kpad), dtype=w.dtype, device=w.device)
@@ -570,7 +579,7 @@ class _FusedConv(torch.autograd.Function):
 
 
 def fused_conv3d(x, w, b=None, stride=1, padding=0, *, x2=None, transposed=False, act=ACT_NONE, slope=0.0,
-                 se=None, res=None, inorm=None, eps=1e-5):
+                 se=None, res=None, inorm=None, eps=1e-5, y_fp32=False):
     """Conv3d / ConvTranspose3d with the fused tails of the hot path.
 
     x2     second tensor of a virtual channel concat (input = cat([x, x2], 1))
@@ -582,7 +591,8 @@ def fused_conv3d(x, w, b=None, stride=1, padding=0, *, x2=None, transposed=False
     mode = "se" if se is not None else ("in" if inorm is not None else "plain")
     if res is not None and mode != "se":
         raise ValueError("res is only fused behind SEGating")
-    cfg = ConvCfg(_triple(stride), _triple(padding), bool(transposed), int(act), float(slope), mode, float(eps))
+    cfg = ConvCfg(_triple(stride), _triple(padding), bool(transposed), int(act), float(slope), mode, float(eps),
+                  bool(y_fp32))
     p1, p2 = (se if se is not None else (inorm if inorm is not None else (None, None)))
     # operand dtype: the thin layers are fp32 kernels; the matrix-core layers follow mixed_precision() / their input
     cin = x.shape[1] + (x2.shape[1] if x2 is not None else 0)

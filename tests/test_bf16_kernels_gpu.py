@@ -334,3 +334,70 @@ def test_sr_head_fp32_routes_to_matrix_cores():
     torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5)
     for a, e in zip(got, want):
         torch.testing.assert_close(a, e, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad", [(1, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)), (1, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+                                                    (2, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3))])
+def test_thin_input_layers_store_bf16_directly(Cin, Cout, K, stride, pad):
+    """Mixed precision: the thin-input layers compute in fp32 on the fp32 image and store bf16 (no cast pass).  The
+    arithmetic is the fp32 kernel's, so the stored values are exactly its results rounded to bf16, the statistics are
+    identical, and the weight gradient from a bf16 dY equals the fp32 kernel's on the same values."""
+    from rehrseg_amd import hip_backend as hb
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, Cin, 5, 40, 70, generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(Cout, Cin, *K, generator=g) / (Cin * K[0] * K[1] * K[2]) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    cfg = ops.ConvCfg(stride, pad, False)
+    y32, st32 = ops.conv_forward(x, None, w, b, cfg, ops.ACT_RELU, 0.0, 2)
+    with ops.mixed_precision():
+        y16, st16 = ops.conv_forward(x, None, w, b, cfg, ops.ACT_RELU, 0.0, 2)
+    assert y16.dtype == torch.bfloat16 and y32.dtype == torch.float32
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+    assert torch.equal(st16, st32)
+    dy = torch.randn(y32.shape, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    assert hb.small_cin_wgrad_on_mfma(x, w, dy, stride, pad)
+    dw16, db16 = ops.conv_wgrad(dy, x, None, w, cfg, True)
+    dw32, db32 = ops.conv_wgrad(dy.float(), x, None, w, cfg, True)
+    assert torch.equal(dw16, dw32) and torch.equal(db16, db32)
+
+
+def test_teacher_window_stem_in_mixed_precision_stores_bf16():
+    """encoder_on_windows under mixed_precision(): the per-slice stem responses stay fp32 (they are combined linearly),
+    the assembled windows are stored as bf16 -- exactly the fp32 assembly rounded."""
+    import torch.nn.functional as Fn
+    from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+    from rehrseg_amd.models.FLAVR.resnet_3D import encoder_on_windows
+    torch.manual_seed(5)
+    enc = UNet_3D_3D(2, "unet_18", 4, 4, use_uncertainty=True).to(DEV).eval().encoder
+    B, D, H, W = 1, 7, 32, 48
+    xp = Fn.pad(torch.randn(B, 2, D, H, W, device=DEV), (0, 0, 0, 0, 1, 2))
+    with torch.no_grad():
+        f32 = encoder_on_windows(enc, xp[:, :, :D + 2], D - 1, 0)[0]
+        with ops.mixed_precision():
+            f16 = encoder_on_windows(enc, xp[:, :, :D + 2], D - 1, 0)[0]
+    assert f16.dtype == torch.bfloat16 and torch.equal(f16, f32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("stats", [False, True])
+def test_split_k_in_mixed_precision(stats):
+    """Low-resolution stage of the nnU-Net plans in bf16 (320 -> 320 at 8 x 5 x 5: a handful of lattice tiles, 8640
+    products per output): the taps run as parts of one gather grid into fp32 slabs, the combine stores bf16 and forms
+    the statistics from the fp32 sums.  Against fp64 on the same bf16-rounded operands, forward and input gradient."""
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(1, 320, 8, 5, 5, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(320, 320, 3, 3, 3, generator=g) / (320 * 27) ** 0.5).to(DEV)
+    b = torch.randn(320, generator=g).to(DEV)
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    assert ops._tap_split((8, 5, 5), 1, 320, [ops.full_taps(3)] * 3, 320, True) is not None
+    y, st = ops.conv_forward(x, None, w, b, cfg, ops.ACT_NONE, 0.0, 2 if stats else 0)
+    assert y.dtype == torch.bfloat16
+    ref = F.conv3d(x.double().cpu(), w.to(torch.bfloat16).double().cpu(), b.double().cpu(), 1, 1)
+    assert relmax(y, ref) < 2.0 ** -7
+    if stats:
+        want = torch.stack([ref.sum((2, 3, 4)), (ref * ref).sum((2, 3, 4))], -1)
+        torch.testing.assert_close(st.cpu(), want, rtol=1e-4, atol=1e-3)
+    dz = torch.randn(1, 320, 8, 5, 5, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    dx = ops.conv_dgrad(dz, w, (8, 5, 5), 320, 0, cfg)[0]
+    xr = x.double().cpu().requires_grad_()
+    F.conv3d(xr, w.to(torch.bfloat16).double().cpu(), None, 1, 1).backward(dz.double().cpu())
+    assert dx.dtype == torch.bfloat16 and relmax(dx, xr.grad) < 2.0 ** -7

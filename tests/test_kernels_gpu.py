@@ -728,3 +728,23 @@ def test_phase_interleaved_grid_is_bit_identical(Cin, Cout, stride, dims, mixed,
         monkeypatch.setattr(hb, "PHASE_INTERLEAVE", flag)
         g[flag] = ops.conv_dgrad(dz, w2, (D, H, W), Cin, 0, cfg2)[0]
     assert torch.equal(g[True], g[False])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("A,B,K", [(64, 64, (3, 3, 3)), (80, 48, (3, 3, 3)), (33, 20, (1, 3, 3)), (320, 256, (2, 2, 2)),
+                                   (64, 64, (37, 3, 3)), (2, 16, (5, 5, 5)), (130, 7, (1, 1, 1))])
+def test_pack_weights_tiled(A, B, K, dtype):
+    """rehr_pack_weights_{f32,bf16} (LDS-tiled: coalesced on both sides) against a torch permute: both source layouts,
+    padded rows zero, tap counts above one 32-tap chunk, ragged tiles."""
+    from rehrseg_amd import hip_backend as hb
+    T = K[0] * K[1] * K[2]
+    Apad = ops.pad_rows(A)
+    for transpose in (False, True):
+        shape = (B, A) + K if transpose else (A, B) + K
+        w = _mk(*shape, seed=300 + A + B).to(_dev())
+        got = hb.pack_weights(w, A, Apad, B, T, transpose, dtype=dtype)
+        src = w.reshape(shape[0], shape[1], T)
+        want = (src.permute(2, 1, 0) if transpose else src.permute(2, 0, 1)).to(dtype)      # [t][a][b]
+        assert tuple(got.shape) == (T, Apad, B)
+        assert torch.equal(got[:, :A], want)
+        assert not got[:, A:].any()
