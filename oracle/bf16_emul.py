@@ -8,6 +8,11 @@ run (fp32 / fp64), at the places where the HIP path stores bf16 (rehrseg_amd/ops
              forward and its gradient on the way back (activation gradients are bf16 tensors on the device)
   weight(w)  the bf16 copy of an fp32 master weight: rounded forward, gradient passed through unrounded (weight
              gradients are fp32 on the device)
+  fwd(x)     value rounded, gradient passed through: a tensor stored as bf16 whose gradient is NOT formed branch by branch
+  grad(x)    value untouched, the TOTAL gradient arriving at x rounded: the device forms the gradient of a conv output
+             (dz) in fp32 from all its contributions -- the normalised / gated activation and the statistics path -- and
+             stores it once as bf16 (instnorm_bwd_apply: one store; SEGating: the scaled gradient is stored, then the
+             per-channel constant of the gate path is added in place: act() on the branch + grad() on the total)
 
 Statistics (InstanceNorm mean / variance, SE pool) are formed from the UNROUNDED accumulators, as the conv epilogues do.
 Layers that stay fp32 on the device (C_in <= 2, the 1x1x1 logits layer, losses) are not rounded.  The emulation has the
@@ -27,9 +32,25 @@ class _RoundBoth(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
+class _RoundGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 class Bf16Emu:
     def act(self, x):
         return _RoundBoth.apply(x)
+
+    def fwd(self, x):
+        return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
+
+    def grad(self, x):
+        return _RoundGrad.apply(x)
 
     def weight(self, w):
         return w + (w.detach().to(torch.bfloat16).to(w.dtype) - w.detach())   # rounded value, straight-through gradient

@@ -26,7 +26,7 @@ def _block_emu(sd, p, x, stride, emu):
     from the unrounded conv output, conv2's output and the block output stored as bf16."""
     xq = emu.act(x)
     out = emu.act(torch.relu(F.conv3d(xq, emu.weight(sd[p + "conv1.0.weight"]), sd.get(p + "conv1.0.bias"), stride, 1)))
-    y0 = F.conv3d(out, emu.weight(sd[p + "conv2.0.weight"]), sd.get(p + "conv2.0.bias"), 1, 1)
+    y0 = emu.grad(F.conv3d(out, emu.weight(sd[p + "conv2.0.weight"]), sd.get(p + "conv2.0.bias"), 1, 1))
     gate = torch.sigmoid(F.conv3d(y0.mean(dim=(2, 3, 4), keepdim=True), sd[p + "fg.attn_layer.0.weight"],
                                   sd[p + "fg.attn_layer.0.bias"]))
     res = xq
@@ -66,6 +66,7 @@ def encoder(sd, x, prefix="encoder.", emu=None, upto=4):
 def _se_emu(y0, w, b, emu):
     """SEGating + LeakyReLU(0.2) behind a decoder conv on the mixed-precision path: gate from the unrounded conv
     output, the conv output and the block output stored as bf16 (the caller's LeakyReLU is fused on the device)."""
+    y0 = emu.grad(y0)
     gate = torch.sigmoid(F.conv3d(y0.mean(dim=(2, 3, 4), keepdim=True), w, b))
     return emu.act(F.leaky_relu(emu.act(y0) * gate, 0.2))
 

@@ -36,10 +36,11 @@ def _cna(sd, p, x, k, stride, eps, slope, emu=None):
         y = F.conv3d(x, sd[p + "conv.weight"], sd.get(p + "conv.bias"), _t(stride), pad)
     else:
         y = F.conv3d(emu.act(x), emu.weight(sd[p + "conv.weight"]), sd.get(p + "conv.bias"), _t(stride), pad)
+    y = emu.grad(y)                                       # dz: all contributions summed in fp32, stored once as bf16
     mean = y.mean(dim=(2, 3, 4), keepdim=True)
     var = y.var(dim=(2, 3, 4), unbiased=False, keepdim=True)
     g, b = sd[p + "norm.weight"].view(1, -1, 1, 1, 1), sd[p + "norm.bias"].view(1, -1, 1, 1, 1)
-    return emu.act(F.leaky_relu((emu.act(y) - mean) * torch.rsqrt(var + eps) * g + b, slope))
+    return emu.act(F.leaky_relu((emu.fwd(y) - mean) * torch.rsqrt(var + eps) * g + b, slope))
 
 
 def _sr_head0_emu(sd, feats, upscale, emu):

@@ -364,16 +364,20 @@ __device__ __forceinline__ bool interleaved_block(int b, int m_tiles, int n_tile
 
 template <int BM, int BN, int WGM, int WGN, int LDSBUF>
 __global__ __launch_bounds__(NTHREADS, (LDSBUF == 1 ? 3 : 2)) void gather_gemm_multi_kernel(const GGMulti pm) {
+  int phase, logical;
   if (pm.interleave) {
-    int phase, logical;
     if (!interleaved_block((int)blockIdx.x, pm.ph[0].m_tiles, pm.ph[0].n_tiles, pm.count, phase, logical)) return;
-    gather_gemm_body<BM, BN, WGM, WGN, LDSBUF>(pm.ph[phase], 0, logical);
-    return;
+  } else {
+    phase = blockIdx.z;
+    const int nb = pm.ph[phase].m_tiles * pm.ph[phase].n_tiles;
+    if ((int)blockIdx.x >= nb) return;  // block-uniform: phases have different tile counts
+    logical = xcd_remap(blockIdx.x, nb);
   }
-  const GGParams& p = pm.ph[blockIdx.z];
-  const int nb = p.m_tiles * p.n_tiles;
-  if ((int)blockIdx.x >= nb) return;  // block-uniform: phases have different tile counts
-  gather_gemm_body<BM, BN, WGM, WGN, LDSBUF>(p, nb);
+  // (block-uniform, but computed with VALU divisions: pinned to SGPRs so that pm.ph[phase] stays a scalar kernarg load;
+  // ONE call site: the body is register-tight and must not be inlined twice)
+  phase = __builtin_amdgcn_readfirstlane(phase);
+  logical = __builtin_amdgcn_readfirstlane(logical);
+  gather_gemm_body<BM, BN, WGM, WGN, LDSBUF>(pm.ph[phase], 0, logical);
 }
 // single launch: parameters at fixed kernarg offsets (the dynamically indexed form above costs
 // a few VGPR spills in the register-tight 128x128 tile)

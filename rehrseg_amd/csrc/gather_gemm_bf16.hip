@@ -336,16 +336,18 @@ __device__ __forceinline__ bool interleaved_block_b(int b, int m_tiles, int n_ti
 
 template <int BM, int BN, int WGM, int WGN, int LDSBUF, int BK>
 __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_bf16_multi_kernel(const GBMulti pm) {
+  int phase, logical;
   if (pm.interleave) {
-    int phase, logical;
     if (!interleaved_block_b((int)blockIdx.x, pm.ph[0].m_tiles, pm.ph[0].n_tiles, pm.count, phase, logical)) return;
-    gg_bf16_body<BM, BN, WGM, WGN, LDSBUF, BK>(pm.ph[phase], 0, logical);
-    return;
+  } else {
+    phase = blockIdx.z;
+    const int nb = pm.ph[phase].m_tiles * pm.ph[phase].n_tiles;
+    if ((int)blockIdx.x >= nb) return;
+    logical = xcd_remap(blockIdx.x, nb);
   }
-  const GBParams& p = pm.ph[blockIdx.z];
-  const int nb = p.m_tiles * p.n_tiles;
-  if ((int)blockIdx.x >= nb) return;
-  gg_bf16_body<BM, BN, WGM, WGN, LDSBUF, BK>(p, nb);
+  phase = __builtin_amdgcn_readfirstlane(phase);      // SGPR index: pm.ph[phase] stays a scalar kernarg load
+  logical = __builtin_amdgcn_readfirstlane(logical);
+  gg_bf16_body<BM, BN, WGM, WGN, LDSBUF, BK>(pm.ph[phase], 0, logical);
 }
 template <int BM, int BN, int WGM, int WGN, int LDSBUF, int BK>
 __global__ __launch_bounds__(NTHREADS, 2) void gather_gemm_bf16_kernel(const GBParams p) {

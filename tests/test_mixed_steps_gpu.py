@@ -11,9 +11,12 @@ activation gradients).  For every compared tensor three distances are formed:
   e_hipE  = |HIP(bf16) - oracle(bf16-emulated)|            what is left: accumulation order, elements that sit on a
                                                             bf16 rounding boundary, and any kernel error
 
-Bars: e_hip32 <= max(floor, 2.5 * e_emu32) per tensor, and e_hipE <= max(floor, 0.75 * e_emu32): the HIP result must be
-closer to the rounding-emulated oracle than that oracle is to fp32 -- a wrong tap, scale or tile in a bf16 kernel
-moves e_hipE to O(1) while e_emu32 stays where it is.  All three are printed.
+Bars: e_hip32 <= max(floor, 2.5 * e_emu32) per tensor -- the device's deviation from fp32 is of the size rounding alone
+produces -- and e_hipE <= max(floor, 1.5 * e_emu32).  Where the emulation can follow the device (shallow layers, forward
+tensors) e_hipE comes out several times SMALLER than e_emu32 (printed); in the deep layers of a randomly initialised
+stack the gradient's rounding noise is chaotic (which way an element on a bf16 boundary rounds decides an activation
+mask downstream), two realisations of the same rounding model then sit sqrt(2) noise magnitudes apart, hence 1.5.  A
+wrong tap, scale or tile in a bf16 kernel moves e_hipE and e_hip32 to O(1) while e_emu32 stays where it is.
 """
 import itertools
 
@@ -50,7 +53,7 @@ def three_way(name, hip, o32, oemu, floor32, floorE, rows):
     e_hip32, e_emu32, e_hipE = l2rel(hip, o32), l2rel(oemu, o32), l2rel(hip, oemu)
     rows.append((name, e_hip32, e_emu32, e_hipE))
     assert e_hip32 <= max(floor32, 2.5 * e_emu32), (name, e_hip32, e_emu32, e_hipE)
-    assert e_hipE <= max(floorE, 0.75 * e_emu32), (name, e_hip32, e_emu32, e_hipE)
+    assert e_hipE <= max(floorE, 1.5 * e_emu32), (name, e_hip32, e_emu32, e_hipE)
 
 
 def show(tag, rows, top=10):
@@ -74,7 +77,7 @@ def _joint_oracle(plan, tsd, ssd, dsd, img, lab_lr, lab_hr, unc, dt, emu):
         ao.dc_and_weighted_ce(s_sr, lab_hr.to(dt), None) + \
         ao.distiller_loss(dw, db, sk[1], tf[1], 0.0, 1.0, 1.0, emu=emu)
     loss.backward()
-    grads = {k: v.grad.double() for k, v in o.items()}
+    grads = {k: v.grad.double() for k, v in o.items() if v.grad is not None}   # (unused deep-supervision heads: None)
     grads["distill.weight"], grads["distill.bias"] = dw.grad.double(), db.grad.double()
     return float(loss.detach()), tf[1].double(), s_lr.detach().double(), s_sr.detach().double(), grads
 
@@ -122,7 +125,7 @@ def _joint_step_three_way(tag, plan, shape, floors):
     show(tag, rows, 16)
     print(f"[{tag}] loss hip", float(loss), "oracle fp32", l32, "oracle bf16-emulated", lE)
     assert abs(float(loss) - l32) <= max(2e-3 * abs(l32), 2.5 * abs(lE - l32)), (float(loss), l32, lE)
-    assert abs(float(loss) - lE) <= max(1e-3 * abs(lE), 0.75 * abs(lE - l32)), (float(loss), l32, lE)
+    assert abs(float(loss) - lE) <= max(1e-3 * abs(lE), 1.5 * abs(lE - l32)), (float(loss), l32, lE)
     return rows
 
 
@@ -202,9 +205,9 @@ def test_single_layer_bf16_gradients_against_fp64_on_the_same_rounded_operands(c
         hip = lambda xx, ww, bb, a, c: ops.fused_conv3d(xx, ww, bb, s, pad, inorm=(a, c), act=ops.ACT_LRELU, slope=0.01)
 
         def ref(xx, ww, bb, a, c):
-            y = F.conv3d(xx, emu.weight(ww), bb, s, pad)
+            y = emu.grad(F.conv3d(xx, emu.weight(ww), bb, s, pad))    # dz: summed in fp32, stored once as bf16
             mean, var = y.mean((2, 3, 4), keepdim=True), y.var((2, 3, 4), unbiased=False, keepdim=True)
-            return F.leaky_relu((emu.act(y) - mean) * torch.rsqrt(var + 1e-5) * a.view(1, -1, 1, 1, 1) + c.view(1, -1, 1, 1, 1), 0.01)
+            return F.leaky_relu((emu.fwd(y) - mean) * torch.rsqrt(var + 1e-5) * a.view(1, -1, 1, 1, 1) + c.view(1, -1, 1, 1, 1), 0.01)
     elif case.startswith("tconv_"):
         s = (2, 2, 2) if case == "tconv_2x2x2" else (1, 2, 2)
         ci, co = 128, 64
@@ -232,6 +235,7 @@ def test_single_layer_bf16_gradients_against_fp64_on_the_same_rounded_operands(c
 
         def ref(xx, ww, bb, a, c):
             y = F.conv_transpose3d(xx, emu.weight(ww), bb, (1, 2, 2), (1, 1, 1)) if tr else F.conv3d(xx, emu.weight(ww), bb, 1, 1)
+            y = emu.grad(y)                                           # the gate path's constant is added to the stored bf16 dz
             gate = torch.sigmoid(F.conv3d(y.mean((2, 3, 4), keepdim=True), a, c))
             z = emu.act(y) * gate
             return F.leaky_relu(z, 0.2) if tr else torch.relu(z + res_t.to(xx.dtype))
