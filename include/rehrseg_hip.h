@@ -117,9 +117,10 @@ typedef struct {
 /* fp32: the 32-channel-tile Winograd kernel forced to two 256-thread blocks per CU / one 512-thread block */
 #define REHR_DBG_GG_W32P_TWO_PER_CU 16
 #define REHR_DBG_GG_W32P_ONE_PER_CU 32
-/* multi-phase launches: blockIdx.z = phase (each phase streams the source once) instead of the phases of a lattice tile
- * as consecutive blocks of one XCD */
-#define REHR_DBG_GG_NO_INTERLEAVE 64
+/* multi-phase launches with equal tile counts: the phases of a lattice tile as consecutive blocks of one XCD instead of
+ * blockIdx.z = phase.  Measured SLOWER (profiles/r03_ab_phase_interleave.txt: +1.4 ms per cfg-3 step, +0.25 ms cfg-5),
+ * kept as a test-selectable organisation only. */
+#define REHR_DBG_GG_INTERLEAVE 64
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);

@@ -343,11 +343,13 @@ constexpr int MAX_PHASES = 8;
 // Several launches that differ only in lattice / taps / destination offset (the stride
 // phases of one transposed conv or strided input gradient) share ONE grid: blockIdx.z picks
 // the phase, so four quarter-size launches fill the chip like one full-size launch.
-// interleave != 0 (all phases have the same tile counts -- kernel = stride transposed convolutions, input gradients
-// of strided convolutions on even extents): a 1-D grid in which the `count` phases of one lattice tile are CONSECUTIVE
-// blocks of ONE XCD, so the tile's source rows come from HBM once and from that XCD's L2 for the other phases (with
-// blockIdx.z = phase the whole source tensor streamed from HBM once per phase: the 64 -> 32 transposed convolution of
-// cfg-3 moved 1.6 GB for 0.67 GB of algorithmic traffic).
+// interleave != 0 (REHR_DBG_GG_INTERLEAVE; all phases have the same tile counts -- kernel = stride transposed
+// convolutions, input gradients of strided convolutions on even extents): a 1-D grid in which the `count` phases of one
+// lattice tile are CONSECUTIVE blocks of ONE XCD, so that the tile's source rows come from HBM once and from that XCD's L2
+// for the other phases (with blockIdx.z = phase the source tensor is streamed once per phase).  Tried in round 3 and
+// measured SLOWER in the step (cfg-3 +1.4 ms, cfg-5 +0.25 ms, profiles/r03_ab_phase_interleave.txt): these launches are
+// bound by block turnover (K = C_in only: two k-steps per block), not by the source re-reads, and eight blocks storing
+// into the same 2x2x2 output neighbourhood at once serialise at the memory side.  Off by default; tests keep it alive.
 struct GGMulti {
   GGParams ph[MAX_PHASES];
   int interleave, count, no_interleave;
@@ -510,7 +512,7 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
   GGMulti pm;
   pm.interleave = 0;
   pm.count = 0;
-  pm.no_interleave = (descs[0].debug_flags & REHR_DBG_GG_NO_INTERLEAVE) ? 1 : 0;
+  pm.no_interleave = (descs[0].debug_flags & REHR_DBG_GG_INTERLEAVE) ? 0 : 1;
   int n = 0;
   for (int i = 0; i < count; ++i) {
     // fewer multiplications beat better tiling: Winograd first -- except for the tap-range parts of a split-K

@@ -472,7 +472,7 @@ extern "C" int rehr_gather_gemm_multi_bf16(const rehr_gather_gemm_desc* descs, i
   GBMulti pm;
   pm.interleave = 0;
   pm.count = 0;
-  pm.no_interleave = (descs[0].debug_flags & REHR_DBG_GG_NO_INTERLEAVE) ? 1 : 0;
+  pm.no_interleave = (descs[0].debug_flags & REHR_DBG_GG_INTERLEAVE) ? 0 : 1;
   int n = 0;
   for (int i = 0; i < count; ++i) {
     int rc = validate(descs[i]);

@@ -700,7 +700,7 @@ def test_uasr_mix(K, D, N, hw):
                                                    (128, 64, (1, 2, 2), (1, 6, 16, 16))])
 def test_phase_interleaved_grid_is_bit_identical(Cin, Cout, stride, dims, mixed, monkeypatch):
     """Kernel = stride transposed convolution (nnU-Net UNetDecoder.transpconvs): the phases of a lattice tile as
-    consecutive blocks of one XCD (default) against blockIdx.z = phase (REHR_DBG_GG_NO_INTERLEAVE) -- the same blocks
+    consecutive blocks of one XCD (REHR_DBG_GG_INTERLEAVE; measured slower, off by default) against blockIdx.z = phase -- the same blocks
     doing the same arithmetic in another order: identical bits, forward and the strided-conv input gradient alike; and
     against fp64."""
     from rehrseg_amd import hip_backend as hb
