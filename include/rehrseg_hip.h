@@ -558,6 +558,13 @@ int rehr_instnorm_act_bwd_bf16(const void* dy, int32_t lddy, const void* x, int3
                                const float* gamma, const float* beta, void* dx, int32_t lddx, float* dgamma,
                                float* dbeta, double* red, int32_t N, int64_t S, int32_t C, int32_t act, float slope,
                                void* stream);
+/* the same, and dconv_bias[c] = sum over all samples and voxels of the dx it writes: the gradient of the bias of the
+ * convolution in front of the normalisation (the mixed-precision weight-gradient kernels carry no bias column; this
+ * replaces a separate rehr_channel_sum_bf16 pass over dx).  dsum: [C] doubles of scratch. */
+int rehr_instnorm_act_bwd_dbias_bf16(const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* mean_rstd,
+                                     const float* gamma, const float* beta, void* dx, int32_t lddx, float* dgamma,
+                                     float* dbeta, double* red, int32_t N, int64_t S, int32_t C, int32_t act,
+                                     float slope, double* dsum, float* dconv_bias, void* stream);
 int rehr_channel_sum_bf16(const void* x, int32_t ldx, int64_t rows, int32_t C, float* out, int32_t accumulate,
                           double* scratch, void* stream);
 int rehr_act_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, int32_t act, float slope, void* stream);

@@ -8,7 +8,6 @@
 // over a block's rows in registers + LDS, and finish with one double atomic per
 // channel per block.
 #include "common.h"
-#include "pack_weights.h"
 
 namespace {
 
@@ -607,11 +606,12 @@ extern "C" const char* rehr_last_hip_error(void) {
 extern "C" int rehr_pack_weights_f32(const float* in, float* out, int32_t A, int32_t Apad, int32_t B,
                                      int32_t T, int32_t transpose_ab, void* stream) {
   if (!in || !out || A < 1 || Apad < A || B < 1 || T < 1) return REHR_EINVAL;
-  if (packw::launch<float>(in, out, A, Apad, B, T, transpose_ab, ST) != REHR_OK) {   // (grid limits: the plain kernel)
-    const int64_t total = (int64_t)T * Apad * B;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, in, out, A,
-                       Apad, B, T, transpose_ab);
-  }
+  // (an LDS-tiled version with coalesced reads was tried in round 3 and measured slower: 19-20 us against 8-11 us per
+  // call -- the strided reads of this kernel are served by the 256 MB Infinity Cache, the tiled kernel had too few blocks
+  // on the small panels: gpurun_out r3f / DESIGN.md section 7)
+  const int64_t total = (int64_t)T * Apad * B;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, in, out, A,
+                     Apad, B, T, transpose_ab);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

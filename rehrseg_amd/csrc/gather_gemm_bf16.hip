@@ -18,7 +18,6 @@
 //  * register-staged pipeline two K steps ahead, branch-free raw buffer loads (out-of-range = zero padding), as
 //    in the fp32 kernel.
 #include "common.h"
-#include "pack_weights.h"
 
 int halo_conv_bf16_try(const rehr_gather_gemm_desc& d, hipStream_t stream);  // halo_conv_bf16.hip
 
@@ -505,12 +504,10 @@ extern "C" int rehr_pack_weights_bf16(const float* in, void* out, int32_t A, int
                                       int32_t transpose_ab, void* stream) {
   if (!in || !out || A < 1 || Apad < A || B < 1 || T < 1) return REHR_EINVAL;
   const int64_t total = (int64_t)T * Apad * B;
-  if (packw::launch<__bf16>(in, reinterpret_cast<__bf16*>(out), A, Apad, B, T, transpose_ab, (hipStream_t)stream) != REHR_OK) {
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in,
-                       reinterpret_cast<__bf16*>(out), A, Apad, B, T, transpose_ab);
-  }
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in,
+                     reinterpret_cast<__bf16*>(out), A, Apad, B, T, transpose_ab);
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }

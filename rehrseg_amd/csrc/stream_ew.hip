@@ -242,14 +242,22 @@ __global__ void instnorm_bwd_params_kernel(const double* __restrict__ red, float
 }
 
 // pass 2: dx = rstd * gamma * (dz - m1 - xhat * m2),  m1 = sum dz / S, m2 = sum dz*xhat / S
-template <typename T>
+// DSUM: also dsum[c] += sum over the block's rows of the dx written -- the gradient of the convolution's bias in front
+// of the normalisation (analytically zero; the reference computes the rounding residue, so does this).  On the
+// mixed-precision path the weight-gradient kernels have no fused bias column, and a separate column-sum pass per layer
+// was 0.74 ms of a cfg-5 step.
+template <typename T, bool DSUM>
 __global__ __launch_bounds__(SW_THREADS) void instnorm_bwd_apply_kernel(
     const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const float* __restrict__ mr,
     const float* __restrict__ gamma, const float* __restrict__ beta, const double* __restrict__ red,
-    T* __restrict__ dx, int lddx, int64_t S, int C, int64_t rows_per_block, double invS, float ga) {
+    T* __restrict__ dx, int lddx, int64_t S, int C, int64_t rows_per_block, double invS, float ga,
+    double* __restrict__ dsum) {
   constexpr int CPT = V16<T>::N;
   const Span s = make_span<CPT>(S, C, rows_per_block);
-  if (!s.active) return;
+  double dacc[1][CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) dacc[0][e] = 0.0;
+  if (s.active) {
   const int n = blockIdx.y;
   float rs[CPT], ms[CPT], g[CPT], b[CPT], k0[CPT], m1[CPT], m2[CPT];
 #pragma unroll
@@ -276,12 +284,45 @@ __global__ __launch_bounds__(SW_THREADS) void instnorm_bwd_apply_kernel(
       const float xh = fmaf(xv[u][e], rs[e], -ms[e]);                          \
       const float dz = fmaf(xh, g[e], b[e]) > 0.f ? dv[u][e] : dv[u][e] * ga;  \
       dv[u][e] = k0[e] * (dz - m1[e] - xh * m2[e]);                            \
+      if (DSUM) fs[e] += dv[u][e];                                             \
     }                                                                          \
     V16<T>::st(dx + (r) * lddx + s.c, dv[u]);                                  \
   }
-  SW_ROW_LOOP(LD_, US_)
+  float fs[CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) fs[e] = 0.f;
+  {
+    // (the row loop of SW_ROW_LOOP, with the fp32 partials folded into fp64 after every unrolled pass)
+    const int64_t step = s.rpp;
+    int64_t r = s.r0 + s.rl;
+    for (; r + (SW_UNROLL - 1) * step < s.r1; r += SW_UNROLL * step) {
+#pragma unroll
+      for (int u = 0; u < SW_UNROLL; ++u) LD_(r + u * step, u)
+#pragma unroll
+      for (int u = 0; u < SW_UNROLL; ++u) US_(r + u * step, u)
+      if (DSUM) {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) { dacc[0][e] += (double)fs[e]; fs[e] = 0.f; }
+      }
+    }
+    for (; r < s.r1; r += step) {
+      LD_(r, 0)
+      US_(r, 0)
+    }
+    if (DSUM) {
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) dacc[0][e] += (double)fs[e];
+    }
+  }
 #undef LD_
 #undef US_
+  }
+  if (DSUM) block_column_atomics<1, CPT>(s, dacc, dsum, 1);
+}
+
+// dconv_bias[c] = dsum[c]
+__global__ void dsum_finish_kernel(const double* __restrict__ dsum, float* __restrict__ out, int C) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) out[c] = (float)dsum[c];
 }
 
 // ---------------------------------------------------------------- y = act(x * gate + res)
@@ -543,7 +584,7 @@ int instnorm_act_fwd_t(const T* x, int ldx, const double* stats, const float* ga
 template <typename T>
 int instnorm_act_bwd_t(const T* dy, int lddy, const T* x, int ldx, const float* mean_rstd, const float* gamma,
                        const float* beta, T* dx, int lddx, float* dgamma, float* dbeta, double* red, int N, int64_t S,
-                       int C, int act, float slope, void* stream) {
+                       int C, int act, float slope, void* stream, double* dsum = nullptr, float* dconv_bias = nullptr) {
   constexpr int CPT = V16<T>::N;
   if (!dy || !x || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red) return REHR_EINVAL;
   if (!shape_ok(N, S, C, CPT) || lddy % CPT || ldx % CPT || lddx % CPT) return REHR_EINVAL;
@@ -554,8 +595,15 @@ int instnorm_act_bwd_t(const T* dy, int lddy, const T* x, int ldx, const float* 
   hipLaunchKernelGGL(instnorm_bwd_reduce_kernel<T>, grid, dim3(SW_THREADS), 0, ST, dy, lddy, x, ldx, mean_rstd, gamma,
                      beta, red, S, C, rpb, ga);
   hipLaunchKernelGGL(instnorm_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, red, dgamma, dbeta, N, C);
-  hipLaunchKernelGGL(instnorm_bwd_apply_kernel<T>, grid, dim3(SW_THREADS), 0, ST, dy, lddy, x, ldx, mean_rstd, gamma,
-                     beta, red, dx, lddx, S, C, rpb, 1.0 / (double)S, ga);
+  if (dsum != nullptr && dconv_bias != nullptr) {
+    if (hipMemsetAsync(dsum, 0, sizeof(double) * C, ST) != hipSuccess) return REHR_EHIP;
+    hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, true>), grid, dim3(SW_THREADS), 0, ST, dy, lddy, x, ldx, mean_rstd,
+                       gamma, beta, red, dx, lddx, S, C, rpb, 1.0 / (double)S, ga, dsum);
+    hipLaunchKernelGGL(dsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, dsum, dconv_bias, C);
+  } else {
+    hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, false>), grid, dim3(SW_THREADS), 0, ST, dy, lddy, x, ldx, mean_rstd,
+                       gamma, beta, red, dx, lddx, S, C, rpb, 1.0 / (double)S, ga, (double*)nullptr);
+  }
   REHR_LAUNCH_CHECK();
   return REHR_OK;
 }
@@ -647,6 +695,15 @@ extern "C" int rehr_instnorm_act_bwd_bf16(const void* dy, int32_t lddy, const vo
                                           int32_t C, int32_t act, float slope, void* stream) {
   return instnorm_act_bwd_t<__bf16>(BF(dy), lddy, BF(x), ldx, mean_rstd, gamma, beta, BFM(dx), lddx, dgamma, dbeta, red,
                                     N, S, C, act, slope, stream);
+}
+extern "C" int rehr_instnorm_act_bwd_dbias_bf16(const void* dy, int32_t lddy, const void* x, int32_t ldx,
+                                                const float* mean_rstd, const float* gamma, const float* beta, void* dx,
+                                                int32_t lddx, float* dgamma, float* dbeta, double* red, int32_t N,
+                                                int64_t S, int32_t C, int32_t act, float slope, double* dsum,
+                                                float* dconv_bias, void* stream) {
+  if (!dsum || !dconv_bias) return REHR_EINVAL;
+  return instnorm_act_bwd_t<__bf16>(BF(dy), lddy, BF(x), ldx, mean_rstd, gamma, beta, BFM(dx), lddx, dgamma, dbeta, red,
+                                    N, S, C, act, slope, stream, dsum, dconv_bias);
 }
 extern "C" int rehr_channel_sum_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out,
                                     int32_t accumulate, double* scratch, void* stream) {

@@ -494,7 +494,9 @@ def instnorm_act_fwd(x, stats, gamma, beta, eps, act, slope):
     return y, mr
 
 
-def instnorm_act_bwd(dy, x, mr, gamma, beta, act, slope):
+def instnorm_act_bwd(dy, x, mr, gamma, beta, act, slope, want_conv_bias=False):
+    """-> (dx, dgamma, dbeta[, dconv_bias]).  want_conv_bias (bf16 only): the column sums of dx -- the gradient of the
+    bias of the convolution in front -- formed inside the apply pass instead of by a separate pass over dx."""
     _chk_dev(dy, x, mr, gamma, beta)
     _same_dtype(dy, x)
     N, S, Cc = _nsc(x)
@@ -502,6 +504,16 @@ def instnorm_act_bwd(dy, x, mr, gamma, beta, act, slope):
     dg = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     red = torch.zeros((N, Cc, 2), dtype=torch.float64, device=x.device)
+    if want_conv_bias:
+        if x.dtype != torch.bfloat16:
+            raise L.RehrsegHipError("the fused conv-bias gradient exists for the bf16 path (fp32: the weight-gradient kernels carry it)")
+        dsum = torch.empty((Cc,), dtype=torch.float64, device=x.device)
+        dcb = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        L.check(L.load().rehr_instnorm_act_bwd_dbias_bf16(_ptr(dy), Cc, _ptr(x), Cc, _ptr(mr), _ptr(gamma), _ptr(beta),
+                                                          _ptr(dx), Cc, _ptr(dg), _ptr(db), _ptr(red), N, S, Cc, act,
+                                                          slope, _ptr(dsum), _ptr(dcb), _stream()),
+                "rehr_instnorm_act_bwd_dbias_bf16")
+        return dx, dg, db, dcb
     fn, name = _fn("rehr_instnorm_act_bwd", x)
     L.check(fn(_ptr(dy), Cc, _ptr(x), Cc, _ptr(mr), _ptr(gamma), _ptr(beta), _ptr(dx), Cc, _ptr(dg), _ptr(db), _ptr(red),
                N, S, Cc, act, slope, _stream()), name)

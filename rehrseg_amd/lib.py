@@ -189,6 +189,8 @@ PROTOTYPES = {
                                              _i32, _f32, _vp]),
     "rehr_instnorm_act_bwd_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                              _i32, _i64, _i32, _i32, _f32, _vp]),
+    "rehr_instnorm_act_bwd_dbias_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                                   _i32, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "rehr_channel_sum_bf16": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp]),
     "rehr_act_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "rehr_abi_version": (C.c_int, []),

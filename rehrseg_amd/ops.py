@@ -557,7 +557,13 @@ class _FusedConv(torch.autograd.Function):
             dp1 = dp1.reshape(p1.shape)
             be.add_channel_const(dz, k)
         else:
-            dz, dp1, dp2 = be.instnorm_act_bwd(dy, y0, mr, p1, p2, cfg.act, cfg.slope)
+            db_in = None
+            if (has_b and ctx.needs_input_grad[3] and y0.dtype == torch.bfloat16 and not cfg.transposed and
+                    hasattr(be, "small_cin_bf16_out_ok")):
+                # mixed precision: the conv-bias gradient (column sums of dz) rides on the InstanceNorm apply pass
+                dz, dp1, dp2, db_in = be.instnorm_act_bwd(dy, y0, mr, p1, p2, cfg.act, cfg.slope, want_conv_bias=True)
+            else:
+                dz, dp1, dp2 = be.instnorm_act_bwd(dy, y0, mr, p1, p2, cfg.act, cfg.slope)
         need = ctx.needs_input_grad
         c1 = x1.shape[1]
         c2 = x2.shape[1] if has_x2 else 0
@@ -565,6 +571,9 @@ class _FusedConv(torch.autograd.Function):
         if need[0] or (has_x2 and need[1]):
             dx1, dx2 = conv_dgrad(dz, w, _spatial(x1), c1, c2, cfg, need[0], has_x2 and need[1], x_dtype=x1.dtype)
         dw = db = None
+        pre_db = db_in if cfg.mode == "in" else None
+        if pre_db is not None:
+            has_b = False                    # (the weight-gradient call below then skips its bias work)
         if need[2] or (has_b and need[3]):
             c1_ = x1.shape[1] + (x2.shape[1] if has_x2 else 0)
             generic = c1_ > 2 and not _thin_out(w, cfg, has_x2)       # the paths that fill a caller-given tensor
@@ -575,6 +584,8 @@ class _FusedConv(torch.autograd.Function):
                 owner.grad_written(param)
             else:
                 dw, db = conv_wgrad(dz, x1, x2, w, cfg, has_b)
+        if pre_db is not None:
+            db = pre_db
         return dx1, dx2, dw, db, dp1, dp2, dres, None
 
 

@@ -401,3 +401,26 @@ def test_split_k_in_mixed_precision(stats):
     xr = x.double().cpu().requires_grad_()
     F.conv3d(xr, w.to(torch.bfloat16).double().cpu(), None, 1, 1).backward(dz.double().cpu())
     assert dx.dtype == torch.bfloat16 and relmax(dx, xr.grad) < 2.0 ** -7
+
+
+def test_instnorm_backward_carries_the_conv_bias_gradient():
+    """rehr_instnorm_act_bwd_dbias_bf16: the apply pass also returns the column sums of the dx it writes (the gradient of
+    the conv bias in front of the normalisation) -- equal to a separate channel sum over dx, same dx / dgamma / dbeta."""
+    from rehrseg_amd import hip_backend as hb
+    g = torch.Generator().manual_seed(77)
+    N, Cc, D, H, W = 2, 96, 5, 18, 14
+    x = act((N, Cc, D, H, W), g)
+    dy = act((N, Cc, D, H, W), g)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(Cc, generator=g) * 0.1).to(DEV)
+    stats = torch.zeros((N, Cc, 2), dtype=torch.float64, device=DEV)
+    xf = x.double()
+    stats[..., 0] = xf.sum((2, 3, 4))
+    stats[..., 1] = (xf * xf).sum((2, 3, 4))
+    _, mr = hb.instnorm_act_fwd(x, stats, gamma, beta, 1e-5, ops.ACT_LRELU, 0.01)
+    dx0, dg0, db0 = hb.instnorm_act_bwd(dy, x, mr, gamma, beta, ops.ACT_LRELU, 0.01)
+    dx1, dg1, db1, dcb = hb.instnorm_act_bwd(dy, x, mr, gamma, beta, ops.ACT_LRELU, 0.01, want_conv_bias=True)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    want = dx1.double().sum((0, 2, 3, 4))
+    scale = float(dx1.double().abs().sum((0, 2, 3, 4)).max())
+    assert float((dcb.double() - want).abs().max()) <= 1e-6 * scale

@@ -733,9 +733,8 @@ def test_phase_interleaved_grid_is_bit_identical(Cin, Cout, stride, dims, mixed,
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("A,B,K", [(64, 64, (3, 3, 3)), (80, 48, (3, 3, 3)), (33, 20, (1, 3, 3)), (320, 256, (2, 2, 2)),
                                    (64, 64, (37, 3, 3)), (2, 16, (5, 5, 5)), (130, 7, (1, 1, 1))])
-def test_pack_weights_tiled(A, B, K, dtype):
-    """rehr_pack_weights_{f32,bf16} (LDS-tiled: coalesced on both sides) against a torch permute: both source layouts,
-    padded rows zero, tap counts above one 32-tap chunk, ragged tiles."""
+def test_pack_weights(A, B, K, dtype):
+    """rehr_pack_weights_{f32,bf16} against a torch permute: both source layouts, padded rows zero."""
     from rehrseg_amd import hip_backend as hb
     T = K[0] * K[1] * K[2]
     Apad = ops.pad_rows(A)
