@@ -282,34 +282,65 @@ __global__ __launch_bounds__(256, (NTM * NTN <= 8) ? 2 : 1) void thin_cin_wgrad_
   const int t_begin = blockIdx.x * p.tiles_per_block;
   const int t_end = min(p.tiles_per_img, t_begin + p.tiles_per_block);
   constexpr int ZV = COUT / 4;                         // float4 pieces per voxel
+  constexpr int NZ = ROWS * COLS * ZV / 256;           // dY pieces per thread (8 or 16)
+  constexpr int NPMAX = NTN >= 10 ? 24 : 8;            // patch floats per thread ((3,7,7) stem: 3 x 13 x 135 / 256 = 21; 3x3x3: 5)
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // software pipeline: the next tile's dY and patch are fetched into registers while the current tile is multiplied
+  f32x4 zr[NZ];
+  float pr[NPMAX];
+  auto fetch = [&](int tile) {
     const int tw = tile % p.tiles_w;
     const int th = (tile / p.tiles_w) % p.tiles_h;
     const int od = tile / (p.tiles_w * p.tiles_h);
     const int oh0 = th * ROWS, ow0 = tw * COLS;
     const int id0 = od * d.sd - d.pd, ih0 = oh0 * d.sh - d.ph, iw0 = ow0 * d.sw - d.pw;
-    __syncthreads();   // the previous tile's LDS reads are done
-    for (int i = tid; i < patch; i += 256) {
-      const int px = i % p.PW, py = (i / p.PW) % p.PH, kd = i / (p.PW * p.PH);
-      const int id = id0 + kd, ih = ih0 + py, iw = iw0 + px;
-      const bool ok = ((unsigned)id < (unsigned)d.Di) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
-      Ps[i] = ok ? xn[(((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NPMAX; ++k) {
+      const int i = tid + 256 * k;
+      float v = 0.f;
+      if (i < patch) {
+        const int px = i % p.PW, py = (i / p.PW) % p.PH, kd = i / (p.PW * p.PH);
+        const int id = id0 + kd, ih = ih0 + py, iw = iw0 + px;
+        const bool ok = ((unsigned)id < (unsigned)d.Di) & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+        if (ok) v = xn[(((int64_t)id * d.Hi + ih) * d.Wi + iw) * d.ldx];
+      }
+      pr[k] = v;
     }
-    for (int i = tid; i < ROWS * COLS * ZV; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const int i = tid + 256 * k;
       const int j = i % ZV, v = i / ZV;
       const int col = v % COLS, row = v / COLS;
       const int oh = oh0 + row, ow = ow0 + col;
       f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (oh < d.Ho && ow < d.Wo)
-        z = load4(zn + (((int64_t)od * d.Ho + oh) * d.Wo + ow) * d.ldy + 4 * j);
-      *reinterpret_cast<f32x4*>(Zs + (size_t)v * p.ZP + 4 * j) = z;
+      if (oh < d.Ho && ow < d.Wo) z = load4(zn + (((int64_t)od * d.Ho + oh) * d.Wo + ow) * d.ldy + 4 * j);
+      zr[k] = z;
     }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < NPMAX; ++k) {
+      const int i = tid + 256 * k;
+      if (i < patch) Ps[i] = pr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const int i = tid + 256 * k;
+      const int j = i % ZV, v = i / ZV;
+      *reinterpret_cast<f32x4*>(Zs + (size_t)v * p.ZP + 4 * j) = zr[k];
+    }
+  };
+
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();   // the previous tile's LDS reads are done
+    stage();
     __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);   // in flight under the MFMAs below
 
     const float* zb = Zs + (size_t)(wave * COLS + kq) * p.ZP + nn;
     const float* pb = Ps + (wave * d.sh) * p.PW + kq * d.sw;
-#pragma unroll 4
+#pragma unroll(NTN >= 10 ? 1 : 4)
     for (int g = 0; g < COLS / 4; ++g) {
       float a[NTM], b[NTN];
 #pragma unroll
@@ -384,6 +415,7 @@ bool thin_cin_wgrad_plan(const rehr_direct_conv_desc& d, ThinCinWgParams& p, dim
   const size_t red = (size_t)4 * 16 * p.NTP * sizeof(float);
   if (smem < red) smem = red;
   if (smem > 150 * 1024) return false;
+  if (d.KD * p.PH * p.PW > (ntn >= 10 ? 24 : 8) * 256) return false;   // the register prefetch holds 24 / 8 patch floats per thread
   p.tiles_h = (d.Ho + 3) / 4;
   p.tiles_w = (d.Wo + 63) / 64;
   const int64_t tpi = (int64_t)d.Do * p.tiles_h * p.tiles_w;
