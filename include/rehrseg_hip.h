@@ -121,6 +121,9 @@ typedef struct {
  * blockIdx.z = phase.  Measured SLOWER (profiles/r03_ab_phase_interleave.txt: +1.4 ms per cfg-3 step, +0.25 ms cfg-5),
  * kept as a test-selectable organisation only. */
 #define REHR_DBG_GG_INTERLEAVE 64
+/* kernel == stride transposed convolutions: the generic one-block-per-(tile, phase) grid instead of the fused kernel
+ * that stages a tile once for all phases (tconv_ks.hip) */
+#define REHR_DBG_GG_NO_TCONV_KS 128
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);

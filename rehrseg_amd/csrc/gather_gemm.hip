@@ -498,6 +498,10 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
       return REHR_EINVAL;  // (y may differ: split-K partials go to separate slabs)
   }
   hipStream_t st = (hipStream_t)stream;
+  if (count > 1) {   // the stride phases of a kernel == stride transposed convolution: one fused launch
+    const int trc = tconv_ks_try(descs, count, false, st);
+    if (trc != REHR_ENOSUP) return trc;
+  }
   if (count > 1 && descs[0].wino_ws != nullptr && (descs[0].td.count > 3 || descs[0].td.count == 1)) {
     // tap-range parts of a split-K launch (many depth taps; or the single depth taps of a layer whose plain Winograd
     // grid would leave half the chip idle): all parts in one Winograd grid, or none

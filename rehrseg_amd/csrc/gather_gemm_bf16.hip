@@ -18,6 +18,7 @@
 //  * register-staged pipeline two K steps ahead, branch-free raw buffer loads (out-of-range = zero padding), as
 //    in the fp32 kernel.
 #include "common.h"
+#include "wino_conv.h"
 
 int halo_conv_bf16_try(const rehr_gather_gemm_desc& d, hipStream_t stream);  // halo_conv_bf16.hip
 
@@ -468,6 +469,14 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ in, __bf16* _
 
 extern "C" int rehr_gather_gemm_multi_bf16(const rehr_gather_gemm_desc* descs, int32_t count, void* stream) {
   if (descs == nullptr || count < 1 || count > MAX_PHASES) return REHR_EINVAL;
+  if (count > 1) {   // the stride phases of a kernel == stride transposed convolution: one fused launch (tconv_ks.hip)
+    bool ok = true;
+    for (int i = 0; i < count && ok; ++i) ok = validate(descs[i]) == REHR_OK;
+    if (ok) {
+      const int trc = tconv_ks_try(descs, count, true, (hipStream_t)stream);
+      if (trc != REHR_ENOSUP) return trc;
+    }
+  }
   GBMulti pm;
   pm.interleave = 0;
   pm.count = 0;

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256, (NTM * NTN <= 8) ? 2 : 1) void thin_cin_wgrad_
 
     const float* zb = Zs + (size_t)(wave * COLS + kq) * p.ZP + nn;
     const float* pb = Ps + (wave * d.sh) * p.PW + kq * d.sw;
-#pragma unroll(NTN >= 10 ? 1 : 4)
+    constexpr int GUNR = NTN >= 10 ? 1 : 4;
+#pragma unroll GUNR
     for (int g = 0; g < COLS / 4; ++g) {
       float a[NTM], b[NTN];
 #pragma unroll

@@ -159,6 +159,7 @@ USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 
 USE_WGRAD_TAP_SKIP = True   # Winograd weight gradient: a depth tap walks only the slices whose source slice exists
 W32P_BLOCKS = 0   # 0: the library picks; 1 / 2 force two 256-thread blocks per CU / one 512-thread block (tests, A/B)
 PHASE_INTERLEAVE = False   # multi-phase launches: the phases of a lattice tile as consecutive blocks of one XCD (measured slower)
+USE_TCONV_KS = True   # kernel == stride transposed convolutions: all phases of an input tile in one block (tconv_ks.hip)
 USE_WINO_FLAT8 = True   # fp32 Winograd on planes that 16 x 16 regions tile badly: wino_flat8_conv_kernel
 WINO_FLAT8_TILES = 0    # 0: the library picks 32 or 64 tiles per block; 1 / 2 force 32 / 64 (tests, A/B)
 wino_wgrad_launches = 0  # weight gradients taken by the Winograd kernel
@@ -213,6 +214,8 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
             d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
     if PHASE_INTERLEAVE:
         d.debug_flags |= L.DBG_GG_INTERLEAVE
+    if not USE_TCONV_KS:
+        d.debug_flags |= L.DBG_GG_NO_TCONV_KS
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0

@@ -28,6 +28,7 @@ DBG_GG_FLAT8_FULL = 8
 DBG_GG_W32P_TWO_PER_CU = 16
 DBG_GG_W32P_ONE_PER_CU = 32
 DBG_GG_INTERLEAVE = 64
+DBG_GG_NO_TCONV_KS = 128
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p

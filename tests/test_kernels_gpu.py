@@ -747,3 +747,30 @@ def test_pack_weights(A, B, K, dtype):
         assert tuple(got.shape) == (T, Apad, B)
         assert torch.equal(got[:, :A], want)
         assert not got[:, A:].any()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("Cin,Cout,stride,dims,bias", [(64, 32, (2, 2, 2), (2, 5, 12, 20), True),     # 2400 voxels: ragged last tile
+                                                        (128, 64, (1, 2, 2), (1, 6, 16, 16), True),
+                                                        (32, 48, (2, 2, 2), (1, 3, 7, 9), False),       # padded C_out rows, no bias
+                                                        (96, 128, (2, 2, 2), (1, 4, 8, 8), True),
+                                                        (128, 96, (2, 1, 2), (2, 3, 5, 6), True)])
+def test_transposed_conv_kernel_equals_stride_fused_kernel(Cin, Cout, stride, dims, bias, mixed, monkeypatch):
+    """tconv_ks.hip (input tile staged once, all stride phases in one block) against the generic one-block-per-(tile, phase)
+    grid and against fp64 on the same operands: forward of nnU-Net's UNetDecoder.transpconvs (seg_model.py:35)."""
+    from rehrseg_amd import hip_backend as hb
+    N, D, H, W = dims
+    dt = torch.bfloat16 if mixed else torch.float32
+    x = _mk(N, Cin, D, H, W, seed=211).to(_dev()).to(dt).contiguous(memory_format=torch.channels_last_3d)
+    w = (_mk(Cin, Cout, *stride, seed=212) / Cin ** 0.5).to(_dev())
+    b = _mk(Cout, seed=213).to(_dev()) if bias else None
+    cfg = ops.ConvCfg(stride, (0, 0, 0), True)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(hb, "USE_TCONV_KS", flag)
+        out[flag] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_NONE, 0.0, 0)[0]
+    assert out[True].dtype == dt
+    _close(out[True].float(), out[False].double().cpu(), 2.0 ** -7 if mixed else 1e-5)
+    wq = w.to(dt).double().cpu() if mixed else w.double().cpu()
+    ref = F.conv_transpose3d(x.double().cpu(), wq, b.double().cpu() if bias else None, stride)
+    _close(out[True].float(), ref, 1e-2 if mixed else TOL)
