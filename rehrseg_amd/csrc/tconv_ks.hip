@@ -256,6 +256,11 @@ __global__ __launch_bounds__(TK_THREADS, 2) void tconv_ks_bf16_kernel(const Tcon
   }
 }
 
+// (A persistent variant with ALL weights of the layer resident in LDS and the next input tile prefetched into registers
+// -- no barrier inside a tile -- was measured in round 3 and lost: one block of 4 waves per CU cannot hide the store and
+// LDS latencies that two or three co-resident streaming blocks hide; 64 -> 32 at 2 x 64^3: 432 us fp32 / 302 us bf16
+// against 345 / 119 us for the kernels above and 450 / 292 us for the generic grid, tools/bench_tconv_ks.py.)
+
 // The `count` descriptors are the stride phases of ONE kernel == stride transposed convolution
 bool tconv_ks_match(const rehr_gather_gemm_desc* ds, int count, bool bf16, TconvKsParams& p) {
   if (count < 2 || count > TK_MAXPH) return false;
@@ -302,6 +307,7 @@ template <int NT>
 int tconv_launch(const TconvKsParams& p, bool bf16, hipStream_t stream) {
   const int64_t blocks = (p.vox_total + TK_BM - 1) / TK_BM;
   if (blocks >= (1ll << 31)) return REHR_ENOSUP;
+  if (!bf16 && p.Cin > 64) return REHR_ENOSUP;   // fp32, 128 input channels: one block per CU (LDS) -- the generic grid is faster
   if (bf16) {
     const size_t smem = ((size_t)TK_BM * p.lda + 2 * NT * 32 * TK_LDH) * 2 + TK_BM * sizeof(int);
     static bool attr = false;
