@@ -19,11 +19,11 @@ for w in flavr_ref flavr seg; do python3 $R/tools/layer_times.py $w > $O/layers_
 fi
 if [ "$PART" = all ] || [ "$PART" = stats ]; then
 for w in flavr seg cfg4 flavr_ref; do
-  prof --kernel-trace --stats --output-format csv -d $O/k_$w -o k -- python3 $R/bench.py --workload $w --steps 5 --warmup 2 $B > $O/k_$w.log 2>&1 || exit 1
+  prof --kernel-trace --stats --output-format csv -d $O/k_$w -o k -- python3 $R/bench.py --workload $w --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_$w.log 2>&1 || exit 1
 done
-prof --kernel-trace --stats --output-format csv -d $O/k_seg_bf16 -o k -- python3 $R/bench.py --workload seg --precision bf16 --steps 5 --warmup 2 $B > $O/k_seg_bf16.log 2>&1 || exit 1
-prof --kernel-trace --stats --output-format csv -d $O/k_cfg5 -o k -- python3 $R/bench.py --workload cfg5 --steps 5 --warmup 2 $B > $O/k_cfg5.log 2>&1 || exit 1
-prof --kernel-trace --stats --output-format csv -d $O/k_flavr_bf16 -o k -- python3 $R/bench.py --workload flavr --precision bf16 --steps 5 --warmup 2 $B > $O/k_flavr_bf16.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_seg_bf16 -o k -- python3 $R/bench.py --workload seg --precision bf16 --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_seg_bf16.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_cfg5 -o k -- python3 $R/bench.py --workload cfg5 --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_cfg5.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_flavr_bf16 -o k -- python3 $R/bench.py --workload flavr --precision bf16 --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_flavr_bf16.log 2>&1 || exit 1
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 for w in flavr seg cfg5; do
