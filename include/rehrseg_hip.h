@@ -124,6 +124,9 @@ typedef struct {
 /* kernel == stride transposed convolutions: the generic one-block-per-(tile, phase) grid instead of the fused kernel
  * that stages a tile once for all phases (tconv_ks.hip) */
 #define REHR_DBG_GG_NO_TCONV_KS 128
+/* fp32 Winograd kernels: tiles in slice-major order (bw, bh, od) instead of the band-major order (bw, od, bh) that keeps
+ * the depth neighbours of a tile on one XCD */
+#define REHR_DBG_GG_SLICE_MAJOR 256
 
 /* scratch bytes the Winograd path needs for this descriptor; 0 = not applicable */
 int64_t rehr_gather_gemm_wino_bytes(const rehr_gather_gemm_desc* d);
@@ -210,6 +213,8 @@ typedef struct {
 /* Winograd weight gradient: walk every output slice for every depth tap (default: a tap skips the slices whose source
  * slice lies outside the volume; tests compare both) */
 #define REHR_DBG_WGRAD_NO_TAP_SKIP 2
+/* Winograd weight gradient: blockIdx.z = depth tap instead of the taps of a split as consecutive blocks of one XCD */
+#define REHR_DBG_WGRAD_NO_TAP_COLOCATE 4
 
 /* Mixed-precision weight gradient: l and g point at bf16 elements (ld* in elements, % 8 == 0; Ca, Cg % 8 == 0),
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 slabs and fp32 dst (the master-weight gradient).  dbias must

@@ -29,6 +29,7 @@ constexpr int NX = (PVOX * 8 + 255) / 256;        // 16-byte pieces staged per t
 struct WinoParams {
   rehr_gather_gemm_desc d;
   int nb_h, nb_w;       // 8 x 16 output regions per depth slice
+  int band_major;       // tile order (bw, od, bh) instead of (bw, bh, od): see the kernels
   int kchunks;
   int dh0, dw0;         // source offset of patch row/col 0 relative to the region origin (= -1 here)
   const float* up;      // U[jd][16][Npad][Cin]
@@ -88,10 +89,15 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoParams p) {
   const int half = lane >> 5, col = lane & 31;
   const int n_img = blockIdx.z;
   const int n0 = blockIdx.y * 32;
+  // Tile order: xcd_remap gives every XCD a contiguous range of logical tiles.  band_major (default): that range walks
+  // DEPTH inside one band of output rows (bw fastest, then od, then bh), so the 64 blocks an XCD has in flight cover
+  // ~8 consecutive slices of one band and the three source slices of a tile are L2 hits left by its depth neighbours
+  // (18 rows x W x 32 channels = 0.3 MB per slice and band against 4 MB of L2).  Slice-major order (bw, bh, od) makes
+  // the in-flight set one whole slice: every source slice is fetched for each of its three depth taps.
   int b = xcd_remap(blockIdx.x, gridDim.x);
   const int bw_ = b % p.nb_w; b /= p.nb_w;
-  const int bh_ = b % p.nb_h;
-  const int od = b / p.nb_h;
+  const int bh_ = p.band_major ? b / p.d.Ld : b % p.nb_h;
+  const int od = p.band_major ? b % p.d.Ld : b / p.nb_h;
   const int oh0 = bh_ * 2 * TH, ow0 = bw_ * 2 * TW;
 
   // B^T rows: (d0 - d2, d1 + d2, d2 - d1, d1 - d3).  The lane computes R = d[i1] + s2 * d[i2]
@@ -375,10 +381,15 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
   const uint32_t up_bytes = (p.nsplit > 1) ? p.s_up_bytes[part] : p.up_bytes;
   float* const yout = (p.nsplit > 1) ? p.s_y[part] : p.d.y;
   const int nt0 = blockIdx.y * 2, n0 = blockIdx.y * 64;
+  // Tile order: xcd_remap gives every XCD a contiguous range of logical tiles.  band_major (default): that range walks
+  // DEPTH inside one band of output rows (bw fastest, then od, then bh), so the 64 blocks an XCD has in flight cover
+  // ~8 consecutive slices of one band and the three source slices of a tile are L2 hits left by its depth neighbours
+  // (18 rows x W x 32 channels = 0.3 MB per slice and band against 4 MB of L2).  Slice-major order (bw, bh, od) makes
+  // the in-flight set one whole slice: every source slice is fetched for each of its three depth taps.
   int b = xcd_remap(blockIdx.x, gridDim.x);
   const int bw_ = b % p.nb_w; b /= p.nb_w;
-  const int bh_ = b % p.nb_h;
-  const int od = b / p.nb_h;
+  const int bh_ = p.band_major ? b / p.d.Ld : b % p.nb_h;
+  const int od = p.band_major ? b % p.d.Ld : b / p.nb_h;
   const int oh0 = bh_ * 16, ow0 = bw_ * 16;
 
   const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
@@ -692,10 +703,15 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 1) void wino_conv_w32p_kernel
   const int half = lane >> 5, col = lane & 31;
   const int n_img = blockIdx.z;
   const int nt0 = blockIdx.y, n0 = blockIdx.y * 32;
+  // Tile order: xcd_remap gives every XCD a contiguous range of logical tiles.  band_major (default): that range walks
+  // DEPTH inside one band of output rows (bw fastest, then od, then bh), so the 64 blocks an XCD has in flight cover
+  // ~8 consecutive slices of one band and the three source slices of a tile are L2 hits left by its depth neighbours
+  // (18 rows x W x 32 channels = 0.3 MB per slice and band against 4 MB of L2).  Slice-major order (bw, bh, od) makes
+  // the in-flight set one whole slice: every source slice is fetched for each of its three depth taps.
   int b = xcd_remap(blockIdx.x, gridDim.x);
   const int bw_ = b % p.nb_w; b /= p.nb_w;
-  const int bh_ = b % p.nb_h;
-  const int od = b / p.nb_h;
+  const int bh_ = p.band_major ? b / p.d.Ld : b % p.nb_h;
+  const int od = p.band_major ? b % p.d.Ld : b / p.nb_h;
   const int oh0 = bh_ * (16 * G), ow0 = bw_ * 16;
 
   const int i1 = (r == 0) ? 0 : 1, i2 = (r == 3) ? 3 : 2;
@@ -1049,6 +1065,7 @@ int wino_conv_split_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t 
   p.up = nullptr;
   p.up_bytes = 0;
   p.nsplit = count;
+  p.band_major = (d0.debug_flags & REHR_DBG_GG_SLICE_MAJOR) ? 0 : 1;
   for (int i = 0; i < count; ++i) {
     const rehr_gather_gemm_desc& d = ds[i];
     if (!d.wino_ws || ((uintptr_t)d.wino_ws & 15)) return REHR_ENOSUP;
@@ -1098,6 +1115,7 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   p.up = d.wino_ws;
   p.up_bytes = (uint32_t)need;
   p.nsplit = 0;
+  p.band_major = (d.debug_flags & REHR_DBG_GG_SLICE_MAJOR) ? 0 : 1;
   if (w32_ok(d)) {
     const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
     int64_t blocks = (total + 255) / 256;

@@ -41,6 +41,7 @@ struct WWParams {
   int a_tiles, c_tiles, Capad, Cgpad;
   int fa, fb;
   bool w8;       // 64 x 64 block of 8 waves (two wave sets)
+  int colocate;  // 1-D (split x tap) grid with the taps of a split on one XCD
   // narrow planes (Lw < 16, e.g. the 12x12 layers of the reference's 96x96 crops): G consecutive (sample, depth)
   // slices are laid side by side, each with a 1-column zero gutter on either side, into a virtual lattice of
   // width G*(Lw+2) -- a pure index map in the fetch; dY is zero in the gutters, so whatever the transform
@@ -91,9 +92,19 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
   const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = wv8 & 3, ws = wv8 >> 2;   // Winograd row, wave set
   const int half = lane >> 5, col = lane & 31;
-  const int split = blockIdx.x;
+  // colocate (default): the depth taps of one split are consecutive blocks of ONE XCD (1-D grid over split x tap):
+  // they walk the same (sample, slice, region) items at the same time, so the dY regions -- and the x slices, which a
+  // tap reads one slice apart from its neighbour -- come from that XCD's L2 for two of the three taps.  With
+  // blockIdx.z = tap the taps of a split sat on different XCDs and every one fetched its own copy (32 x 32 channels at
+  // 2 x 128^3: 3.99 GB per launch for 1.07 GB of operands, 3.7 TB/s at the memory side).
+  int split = blockIdx.x, jd = blockIdx.z;
+  if (p.colocate) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    jd = __builtin_amdgcn_readfirstlane(j % d.td.count);
+    split = __builtin_amdgcn_readfirstlane((j / d.td.count) * 8 + xcd);
+    if (split >= p.splits) return;   // (block-uniform padding block)
+  }
   const int at = blockIdx.y / p.c_tiles, ct = blockIdx.y - at * p.c_tiles;
-  const int jd = blockIdx.z;
   const int ca0 = at * (FA * WS * 32), cg0 = ct * (FB * 32);
   const int doff = d.bd + d.td.off0 + d.td.offs * jd;
   // output slices this tap reaches, and its share of the split-K walk
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
   } else {
     items_tap = d.N * nod * p.nb_h * p.nb_w;
   }
-  const int ips = p.skip ? (items_tap + (int)gridDim.x - 1) / (int)gridDim.x : p.items_per_split;
+  const int ips = p.skip ? (items_tap + p.splits - 1) / p.splits : p.items_per_split;
   const int it0 = split * ips;
   const int it1 = min(it0 + ips, p.skip ? items_tap : p.items);
   const int nstages = max(0, it1 - it0);
@@ -609,6 +620,9 @@ bool plan(const rehr_wgrad_desc& d, WWParams& p) {
     const double eff = (double)blocks / (double)(rounds * slots);
     if (eff > best_eff + 0.03) { best_eff = eff; best_s = s; }
   }
+  // many splits (few channel tiles, e.g. 32 x 32 channels: 170): a multiple of 8, so that the tap-colocated grid (the
+  // taps of a split on one XCD, see the kernel) gives every XCD the same number of blocks
+  if (best_s >= 64 && d.td.count > 1) best_s &= ~7;
   p.splits = best_s;
   p.items_per_split = (p.items + p.splits - 1) / p.splits;
   p.splits = (p.items + p.items_per_split - 1) / p.items_per_split;
@@ -636,7 +650,10 @@ int wino_wgrad_try(const rehr_wgrad_desc& d, hipStream_t stream) {
   if (!d.workspace || d.workspace_bytes < need || ((uintptr_t)d.workspace & 15)) return REHR_EINVAL;
   p.slabs = d.workspace;
   p.slab_bias = d.dbias ? d.workspace + slab_floats(p) : nullptr;
+  // (only with many splits in whole groups of 8: with a handful of splits the valid blocks would pile up on a few XCDs)
+  p.colocate = (d.td.count > 1 && p.splits >= 64 && p.splits % 8 == 0 && !(d.debug_flags & REHR_DBG_WGRAD_NO_TAP_COLOCATE)) ? 1 : 0;
   dim3 grid(p.splits, p.a_tiles * p.c_tiles, d.td.count);
+  if (p.colocate) grid = dim3((unsigned)(((p.splits + 7) / 8) * 8 * d.td.count), p.a_tiles * p.c_tiles, 1);
   int rc;
   const bool virt = p.G != 0;
   if (p.w8) rc = virt ? launch_ww<1, 2, true, 1, 2>(p, grid, stream) : launch_ww<1, 2, false, 1, 2>(p, grid, stream);

@@ -156,9 +156,11 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
 USE_WINOGRAD = True
 USE_WINOGRAD_WGRAD = True   # False -> REHR_DBG_WGRAD_DIRECT
 USE_HALO_BF16 = True   # mixed precision: LDS halo-brick kernel for unit-stride 3x3(x3) taps (False -> REHR_DBG_GG_NO_HALO)
+WGRAD_TAP_COLOCATE = True   # Winograd weight gradient: the depth taps of a split on one XCD (shared dY / x in L2)
 USE_WGRAD_TAP_SKIP = True   # Winograd weight gradient: a depth tap walks only the slices whose source slice exists
 W32P_BLOCKS = 0   # 0: the library picks; 1 / 2 force two 256-thread blocks per CU / one 512-thread block (tests, A/B)
 PHASE_INTERLEAVE = False   # multi-phase launches: the phases of a lattice tile as consecutive blocks of one XCD (measured slower)
+WINO_BAND_MAJOR = True   # fp32 Winograd tile order: an XCD walks depth inside a band of rows (L2 reuse of the depth taps)
 USE_TCONV_KS = True   # kernel == stride transposed convolutions: all phases of an input tile in one block (tconv_ks.hip)
 USE_WINO_FLAT8 = True   # fp32 Winograd on planes that 16 x 16 regions tile badly: wino_flat8_conv_kernel
 WINO_FLAT8_TILES = 0    # 0: the library picks 32 or 64 tiles per block; 1 / 2 force 32 / 64 (tests, A/B)
@@ -216,6 +218,8 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
         d.debug_flags |= L.DBG_GG_INTERLEAVE
     if not USE_TCONV_KS:
         d.debug_flags |= L.DBG_GG_NO_TCONV_KS
+    if not WINO_BAND_MAJOR:
+        d.debug_flags |= L.DBG_GG_SLICE_MAJOR
     d._keep = keep  # scratch stays referenced until the launch has been enqueued
     _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
@@ -306,7 +310,8 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
     d.accumulate = int(accumulate)
     d.dbias = _ptr(dbias)
     d.flags = 0
-    d.debug_flags = (0 if USE_WINOGRAD_WGRAD else L.DBG_WGRAD_DIRECT) | (0 if USE_WGRAD_TAP_SKIP else L.DBG_WGRAD_NO_TAP_SKIP)
+    d.debug_flags = ((0 if USE_WINOGRAD_WGRAD else L.DBG_WGRAD_DIRECT) | (0 if USE_WGRAD_TAP_SKIP else L.DBG_WGRAD_NO_TAP_SKIP) |
+                     (0 if WGRAD_TAP_COLOCATE else L.DBG_WGRAD_NO_TAP_COLOCATE))
     lib = L.load()
     flops = _algo_flops(N, lattice, s, b, taps, g_dims, Ca, Cg) if _prof is not None else 0.0
     if bf16:

@@ -21,6 +21,7 @@ GG_Y_F32 = 1            # rehr_gather_gemm_desc.flags
 # debug_flags (unstable; tests and A/B tools only -- 0 selects the measured-best kernels)
 DBG_WGRAD_DIRECT = 1    # rehr_wgrad_desc.debug_flags
 DBG_WGRAD_NO_TAP_SKIP = 2
+DBG_WGRAD_NO_TAP_COLOCATE = 4
 DBG_GG_NO_HALO = 1      # rehr_gather_gemm_desc.debug_flags
 DBG_GG_NO_FLAT8 = 2
 DBG_GG_FLAT8_HALF = 4
@@ -29,6 +30,7 @@ DBG_GG_W32P_TWO_PER_CU = 16
 DBG_GG_W32P_ONE_PER_CU = 32
 DBG_GG_INTERLEAVE = 64
 DBG_GG_NO_TCONV_KS = 128
+DBG_GG_SLICE_MAJOR = 256
 
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 _vp = C.c_void_p

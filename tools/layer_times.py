@@ -11,6 +11,8 @@ from rehrseg_amd.train_steps import train_sr_step  # noqa: E402
 from rehrseg_amd.utils.seg_utils import BCEDiceLoss  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "flavr_ref"
+mixed = which.endswith("_bf16")          # e.g. seg_bf16: the same workload under ops.mixed_precision()
+which = which[:-5] if mixed else which
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
 torch.manual_seed(0)
@@ -46,6 +48,13 @@ else:
         opt.zero_grad(set_to_none=True)
         (model(x.clone()) - tgt).abs().mean().backward()
         opt.step()
+if mixed:
+    from rehrseg_amd import ops  # noqa: E402
+    plain_step = step
+
+    def step():
+        with ops.mixed_precision():
+            plain_step()
 for _ in range(3):
     step()
 acc = collections.OrderedDict()
@@ -61,5 +70,5 @@ for _ in range(REP):
 rows = sorted(acc.items(), key=lambda kv: -kv[1][2])
 tot = sum(v[2] for _, v in rows) / REP
 print(f"matrix-core launches: {tot * 1e3:.2f} ms/step")
-for (fam, tag), (n, fl, sec) in rows[:40]:
+for (fam, tag), (n, fl, sec) in rows[:60]:
     print(f"{sec / REP * 1e3:7.3f} ms  x{n // REP:<2d} {fl / sec / 1e12:6.1f} TF alg  {fam:13s} {tag}")
