@@ -774,3 +774,45 @@ def test_transposed_conv_kernel_equals_stride_fused_kernel(Cin, Cout, stride, di
     wq = w.to(dt).double().cpu() if mixed else w.double().cpu()
     ref = F.conv_transpose3d(x.double().cpu(), wq, b.double().cpu() if bias else None, stride)
     _close(out[True].float(), ref, 1e-2 if mixed else TOL)
+
+
+@pytest.mark.parametrize("Cin,Cout,dims", [(32, 32, (2, 7, 48, 40)), (64, 64, (1, 5, 32, 48)), (48, 32, (1, 3, 33, 50))])
+def test_winograd_tile_orders_are_bit_identical(Cin, Cout, dims, monkeypatch):
+    """Band-major tile order (an XCD walks depth inside a band of rows: default) against slice-major
+    (REHR_DBG_GG_SLICE_MAJOR): the same tiles in another order -> the same bits, statistics to summation order."""
+    from rehrseg_amd import hip_backend as hb
+    N, D, H, W = dims
+    x = _mk(N, Cin, D, H, W, seed=221).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = (_mk(Cout, Cin, 3, 3, 3, seed=222) / (27 * Cin) ** 0.5).to(_dev())
+    b = _mk(Cout, seed=223).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(hb, "WINO_BAND_MAJOR", flag)
+        before = hb.wino_launches
+        out[flag] = ops.conv_forward(x, None, w, b, cfg, ops.ACT_LRELU, 0.01, 2)
+        assert hb.wino_launches > before
+    assert torch.equal(out[True][0], out[False][0])
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-9, atol=1e-6)
+
+
+def test_winograd_wgrad_tap_colocation_is_bit_identical(monkeypatch):
+    """The depth taps of a split as consecutive blocks of one XCD (default where the splits come in whole groups of 8)
+    against blockIdx.z = tap: the same blocks, the same slabs, the same fixed-order reduction."""
+    from rehrseg_amd import hip_backend as hb
+    x = _mk(2, 32, 24, 64, 64, seed=231).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    dy = _mk(2, 32, 24, 64, 64, seed=232).to(_dev()).contiguous(memory_format=torch.channels_last_3d)
+    w = _mk(32, 32, 3, 3, 3, seed=233).to(_dev())
+    cfg = ops.ConvCfg((1, 1, 1), (1, 1, 1), False)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(hb, "WGRAD_TAP_COLOCATE", flag)
+        before = hb.wino_wgrad_launches
+        out[flag] = ops.conv_wgrad(dy, x, None, w, cfg, True)
+        assert hb.wino_wgrad_launches - before == 1
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    xr, wr = x.double().cpu(), w.double().cpu().requires_grad_()
+    br = torch.zeros(32, dtype=torch.float64, requires_grad=True)
+    rw, rb = torch.autograd.grad(F.conv3d(xr, wr, br, 1, 1), [wr, br], dy.double().cpu())
+    _close(out[True][0], rw)
+    _close(out[True][1], rb)
