@@ -126,6 +126,31 @@ def _same_dtype(*ts):
         raise L.RehrsegHipError(f"activation operands of one call must share a dtype, got {sorted(map(str, dts))}")
 
 
+# Small zero-initialised fp64 accumulators (per-(sample, channel) statistics, gradient reductions): every fused layer
+# needs one or two per pass, and a torch.zeros() each is a 5 us fill launch -- ~90 per cfg-2 step.  They are carved out
+# of a pooled chunk that is zeroed by ONE fill when it is allocated; a slice is handed out once and never reused (the
+# chunk lives as long as any slice of it does), so no kernel ever sees stale values.
+_zero_pool = {}
+_ZERO_CHUNK = 1 << 16   # doubles (512 KB)
+
+
+def zeros_f64(shape, device):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    n_al = (n + 1) & ~1                                   # keep 16-byte alignment of every slice
+    if n_al > _ZERO_CHUNK // 4:
+        return torch.zeros(shape, dtype=torch.float64, device=device)
+    key = (device.type, device.index)
+    ent = _zero_pool.get(key)
+    if ent is None or ent[1] + n_al > _ZERO_CHUNK:
+        ent = [torch.zeros(_ZERO_CHUNK, dtype=torch.float64, device=device), 0]
+        _zero_pool[key] = ent
+    out = ent[0][ent[1]:ent[1] + n].view(shape)
+    ent[1] += n_al
+    return out
+
+
 def new_act(N, Cc, D, H, W, like, zero=False, dtype=None):
     """NDHWC activation in `like`'s dtype (fp32, or bf16 on the mixed-precision path) unless `dtype` says otherwise."""
     dt = dtype if dtype is not None else (like.dtype if like.dtype == torch.bfloat16 else torch.float32)
@@ -466,7 +491,7 @@ def scale_res_act_bwd(dy, y, x, gate, want_dres, act, slope):
     N, S, Cc = _nsc(x)
     dx = new_act(*x.shape, like=x)
     dres = new_act(*x.shape, like=x) if want_dres else None
-    dgate = torch.zeros((N, Cc), dtype=torch.float64, device=x.device)
+    dgate = zeros_f64((N, Cc), x.device)
     fn, name = _fn("rehr_scale_res_act_bwd", x)
     L.check(fn(_ptr(dy), Cc, _ptr(y), Cc, _ptr(x), Cc, _ptr(gate), _ptr(dx), Cc, _ptr(dres), Cc, _ptr(dgate), N, S, Cc,
                act, slope, _stream()), name)
@@ -511,7 +536,7 @@ def instnorm_act_bwd(dy, x, mr, gamma, beta, act, slope, want_conv_bias=False):
     dx = new_act(*x.shape, like=x)
     dg = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-    red = torch.zeros((N, Cc, 2), dtype=torch.float64, device=x.device)
+    red = zeros_f64((N, Cc, 2), x.device)
     if want_conv_bias:
         if x.dtype != torch.bfloat16:
             raise L.RehrsegHipError("the fused conv-bias gradient exists for the bf16 path (fp32: the weight-gradient kernels carry it)")

@@ -282,7 +282,10 @@ def conv_forward(x1, x2, w, bias, cfg: ConvCfg, act, slope, stats_mode):
     Cout = w.shape[1] if cfg.transposed else w.shape[0]
     if (w.shape[0] if cfg.transposed else w.shape[1]) != Cin:
         raise ValueError(f"weight {tuple(w.shape)} does not match {Cin} input channels")
-    stats = torch.zeros((N, Cout, 2), dtype=torch.float64, device=x1.device) if stats_mode else None
+    stats = None
+    if stats_mode:
+        stats = (be.zeros_f64((N, Cout, 2), x1.device) if hasattr(be, "zeros_f64")
+                 else torch.zeros((N, Cout, 2), dtype=torch.float64, device=x1.device))
     if Cin <= 2:
         if cfg.transposed or x2 is not None:
             raise ValueError("thin-input path handles plain Conv3d only")
