@@ -1,5 +1,5 @@
 """A/B of one hip_backend switch inside a bench.py workload (GPU box):
-    python tools/ab_flag.py USE_WINO_8WAVE flavr [extra bench args]"""
+    python tools/ab_flag.py WINO_BAND_MAJOR flavr [extra bench args]"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flag, workload, extra = sys.argv[1], sys.argv[2], sys.argv[3:]

@@ -1,3 +1,5 @@
+# (run at the start of round 3, BEFORE the superseded kernel organisations were deleted: the hip_backend switches it
+# flips no longer exist; kept as the record of how profiles/r03_ab_superseded.txt was produced)
 # Round 3, first call: (1) the driver's 20-step command against the 100-step default,
 # (2) A/B of every kernel organisation that round 2 superseded, on the workload that uses it, before their removal.
 # bash tools/collect_r03_ab.sh   (GPU box, repo root)
