@@ -538,6 +538,7 @@ class _FusedConv(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has = (x2 is not None, b is not None, res is not None)
         ctx.save_for_backward(x1, x2, w, p1, p2, y0, y, gate, mean, mr)
+        ctx.bias_ref = weakref.ref(b) if isinstance(b, torch.nn.Parameter) else None
         if _direct_grad and ctx.needs_input_grad[2]:
             _note_use(w)
         return y
@@ -583,9 +584,34 @@ class _FusedConv(torch.autograd.Function):
             tgt = _direct_grad_target(w) if (need[2] and generic) else None
             if tgt is not None:
                 param, owner, gview = tgt
-                _, db = conv_wgrad(dz, x1, x2, w, cfg, has_b, out=gview)
-                owner.grad_written(param)
+                side = owner.wgrad_stream() if (dz.is_cuda and hasattr(owner, "wgrad_stream")) else None
+                if side is not None and has_b:
+                    # the bias gradient comes back as a tensor: safe on the side stream only if autograd hands it over
+                    # (parameter's .grad is None) instead of accumulating into it on the main stream
+                    bp = ctx.bias_ref() if ctx.bias_ref is not None else None
+                    if bp is None or bp.grad is not None:
+                        side = None
+                if side is not None:
+                    # the weight gradient does not feed the layer below: launch it on the owner's side stream, behind an
+                    # event that marks dz complete; the main stream goes on with the input-gradient chain
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    owner.note_side_launch(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        _, db = conv_wgrad(dz, x1, x2, w, cfg, has_b, out=gview)
+                        owner.grad_written(param)
+                    for t in (dz, x1, x2):
+                        if t is not None:
+                            t.record_stream(side)     # their memory is not recycled before the side stream is done
+                else:
+                    _, db = conv_wgrad(dz, x1, x2, w, cfg, has_b, out=gview)
+                    owner.grad_written(param)
             else:
+                if _direct_grad and need[2]:
+                    ent = _direct_entry(w)
+                    if ent is not None and hasattr(ent[1], "join_side"):
+                        ent[1].join_side()   # autograd will accumulate into a slot a side-stream kernel may be writing
                 dw, db = conv_wgrad(dz, x1, x2, w, cfg, has_b)
         if pre_db is not None:
             db = pre_db

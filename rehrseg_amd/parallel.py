@@ -22,6 +22,16 @@ A gradient reaches its slot by one of three routes:
 and whatever `.grad` holds when a bucket is exchanged is reconciled with the slot (`_collect`): a tensor that
 is not the view is copied in and the view restored, a missing gradient contributes zeros -- so a plain
 `optimizer.zero_grad()` (set_to_none=True) between steps is safe too.
+
+Weight gradients on a second HIP stream (`wgrad_stream=True`, default on the device).  In the backward of a layer
+the weight gradient does not feed the chain to the layer below -- only the input gradient does.  The direct-route
+weight-gradient kernels are therefore launched on a side stream (after an event that marks dz complete) while the main
+stream goes on with the input gradient and the HBM-bound InstanceNorm / SEGating passes of the next layer down: the
+matrix-core kernel of one stream fills the tail rounds and the memory-bound passes of the other (cfg-3: 47.6 -> 43.3 ms
+per step, cfg-2: 61.6 -> 60.2, tools/exp_side_stream.py).  Nothing reads a side-stream result before the join in
+`reduce_gradients()`: the kernels write into the flat buffer (no autograd accumulation), bias gradients are handed over
+to parameters whose `.grad` is None, and a bucket's all-reduce launched from the side stream first waits for the main
+one.  Same kernels, same operands, same results.
 """
 from __future__ import annotations
 
@@ -31,7 +41,7 @@ import torch.distributed as dist
 
 class PatchParallel:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 64, process_group=None, overlap: bool = True,
-                 force_overlap: bool = False, direct=None):
+                 force_overlap: bool = False, direct=None, wgrad_stream: bool = True):
         """force_overlap: take the hook-launched bucket path even with a single rank (tests: the exchange code
         then runs, over a world-1 group, exactly as it does on 8 GPUs).
         direct: the parameters whose gradient the weight-gradient kernels may write in place (default: every
@@ -77,6 +87,11 @@ class PatchParallel:
         if force_overlap and not dist.is_initialized():
             raise ValueError("force_overlap needs an initialised process group (world size 1 is fine)")
         self.overlap = overlap and self.exchange
+        # second stream for the direct-route weight gradients (see the module docstring); device parameters only
+        self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._side = self._side_stream if wgrad_stream else None
+        self._side_used = False
+        self._main = None
         self._reset_step()
         if self.overlap:
             for p in self.params:
@@ -121,8 +136,38 @@ class PatchParallel:
         if src:
             torch._foreach_copy_(dst, src)
 
+    def wgrad_stream(self):
+        """The side stream the direct-route weight-gradient kernels run on (None: everything on the current stream)."""
+        return self._side
+
+    def set_wgrad_stream(self, enabled: bool):
+        """Switch the side stream on / off between steps (bench.py times the kernels one by one with it off: the
+        duration of a kernel that shares the chip with another stream's kernel says nothing about the kernel)."""
+        self._join_side()
+        self._side = self._side_stream if enabled else None
+
+    def note_side_launch(self, main_stream):
+        """A kernel is about to be launched on the side stream; `main_stream` is the stream the backward runs on."""
+        self._side_used = True
+        self._main = main_stream
+
+    def join_side(self):
+        """Public form of the join: called before a gradient that a side-stream kernel may still be writing is touched
+        on the main stream (a second backward pass accumulating into a directly written weight gradient)."""
+        self._join_side()
+
+    def _join_side(self):
+        """Main stream waits for everything launched on the side stream (before gradients are read on the main one)."""
+        if self._side is not None and self._side_used:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            self._side_used = False
+
     def _launch(self, i):
         s, e = self.buckets[i]
+        if self._side is not None and self._main is not None and torch.cuda.current_stream(self._side.device) == self._side:
+            # launched from the side stream (a kernel there completed the bucket): the other gradients of the bucket
+            # were produced on the main stream
+            self._side.wait_stream(self._main)
         self._collect(i)
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._launched[i] = True
@@ -169,6 +214,7 @@ class PatchParallel:
         Buckets whose hooks did not fire (parameters without a gradient this step, or
         overlap disabled) are exchanged here.  Ends the step's bookkeeping, so the next backward
         starts clean whether or not `zero_grad()` of this object is called in between."""
+        self._join_side()
         if not self.exchange:
             # single rank: handed-over gradients stay where autograd put them (the optimizer reads p.grad)
             self._written.clear()

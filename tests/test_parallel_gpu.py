@@ -115,3 +115,36 @@ def test_hook_launched_buckets_with_direct_writes_under_rccl_world1(tmp_path):
     # every bucket whose parameters all received a gradient went out from a hook before reduce_gradients
     assert min(res["launched"]) >= res["buckets"] - 2, res
     assert res["written"][0] >= 20 and res["written"][1] == 0 and res["written"][2] >= 20, res
+
+
+def test_side_stream_weight_gradients_change_nothing():
+    """PatchParallel(wgrad_stream=True): the direct-route weight-gradient kernels run on a second HIP stream while the
+    main stream continues with the input-gradient chain.  Same kernels on the same operands: after the join in
+    reduce_gradients() every gradient -- and, after three optimizer steps, every parameter -- is bit-identical to the
+    single-stream run; a second accumulated backward pass (autograd accumulates into directly written slots) too."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 2, 4, 48, 40, generator=g).to(dev)
+    res = {}
+    for side in (False, True):
+        m = _model(dev)
+        pp = PatchParallel(m, wgrad_stream=side)
+        assert (pp.wgrad_stream() is not None) == side
+        opt = torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.9)
+        for _ in range(3):
+            pp.zero_grad()
+            m(x.clone()).abs().mean().backward()
+            pp.reduce_gradients()
+            opt.step()
+        pp.zero_grad()
+        for _ in range(2):                                   # accumulation over two passes
+            m(x.clone()).abs().mean().backward()
+        pp.reduce_gradients()
+        torch.cuda.synchronize()
+        res[side] = ({n: p.detach().clone() for n, p in m.named_parameters()},
+                     {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        pp.close()
+    for n in res[False][0]:
+        assert torch.equal(res[False][0][n], res[True][0][n]), n
+    for n in res[False][1]:
+        assert torch.equal(res[False][1][n], res[True][1][n]), n
