@@ -164,12 +164,20 @@ class PatchParallel:
 
     def _launch(self, i):
         s, e = self.buckets[i]
-        if self._side is not None and self._main is not None and torch.cuda.current_stream(self._side.device) == self._side:
-            # launched from the side stream (a kernel there completed the bucket): the other gradients of the bucket
-            # were produced on the main stream
-            self._side.wait_stream(self._main)
-        self._collect(i)
-        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._side is not None and self._side_used:
+            # Gradients of this bucket may come from BOTH streams (a parameter counts as ready when its kernel has been
+            # LAUNCHED).  The exchange is issued from the side stream after that stream has caught up with the other
+            # one: RCCL orders itself behind the issuing stream, the main stream is not held up.
+            cur = torch.cuda.current_stream(self._side.device)
+            other = self._main if cur == self._side else cur
+            if other is not None:
+                self._side.wait_stream(other)
+            with torch.cuda.stream(self._side):
+                self._collect(i)
+                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._collect(i)
+            self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._launched[i] = True
 
     def _on_grad_ready(self, p):

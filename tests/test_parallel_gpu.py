@@ -120,13 +120,16 @@ def test_hook_launched_buckets_with_direct_writes_under_rccl_world1(tmp_path):
 def test_side_stream_weight_gradients_change_nothing():
     """PatchParallel(wgrad_stream=True): the direct-route weight-gradient kernels run on a second HIP stream while the
     main stream continues with the input-gradient chain.  Same kernels on the same operands: after the join in
-    reduce_gradients() every gradient -- and, after three optimizer steps, every parameter -- is bit-identical to the
-    single-stream run; a second accumulated backward pass (autograd accumulates into directly written slots) too."""
+    reduce_gradients() every gradient -- and, after three optimizer steps, every parameter -- equals the single-stream
+    run to the run-to-run reproducibility of the path (the fp64 statistics atomics of the SEGating epilogues commute
+    only up to rounding: two single-stream runs differ by the same few ulp, measured alongside); a second accumulated
+    backward pass (autograd accumulates into directly written slots) too.  A race would show as O(1) errors."""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
     x = torch.rand(2, 2, 4, 48, 40, generator=g).to(dev)
     res = {}
-    for side in (False, True):
+    for side in (False, True, "again"):
+        tag, side = side, bool(side) if side != "again" else False
         m = _model(dev)
         pp = PatchParallel(m, wgrad_stream=side)
         assert (pp.wgrad_stream() is not None) == side
@@ -141,10 +144,14 @@ def test_side_stream_weight_gradients_change_nothing():
             m(x.clone()).abs().mean().backward()
         pp.reduce_gradients()
         torch.cuda.synchronize()
-        res[side] = ({n: p.detach().clone() for n, p in m.named_parameters()},
-                     {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        res[tag] = ({n: p.detach().clone() for n, p in m.named_parameters()},
+                    {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
         pp.close()
-    for n in res[False][0]:
-        assert torch.equal(res[False][0][n], res[True][0][n]), n
-    for n in res[False][1]:
-        assert torch.equal(res[False][1][n], res[True][1][n]), n
+
+    def dist_(a, b):
+        return max(float((a[n] - b[n]).abs().max()) / (float(a[n].abs().max()) + 1e-30) for n in a)
+    for k in (0, 1):
+        repro = dist_(res[False][k], res["again"][k])           # two single-stream runs
+        d = dist_(res[False][k], res[True][k])
+        print("side stream vs single stream:", "parameters" if k == 0 else "gradients", d, "run-to-run", repro)
+        assert d <= max(1e-5, 4 * repro), (k, d, repro)
