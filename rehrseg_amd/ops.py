@@ -581,9 +581,18 @@ class _FusedConv(torch.autograd.Function):
         if need[2] or (has_b and need[3]):
             c1_ = x1.shape[1] + (x2.shape[1] if has_x2 else 0)
             generic = c1_ > 2 and not _thin_out(w, cfg, has_x2)       # the paths that fill a caller-given tensor
-            tgt = _direct_grad_target(w) if (need[2] and generic) else None
+            tgt = _direct_grad_target(w) if need[2] else None
             if tgt is not None:
                 param, owner, gview = tgt
+
+                def run_wgrad():
+                    if generic:
+                        _, db_ = conv_wgrad(dz, x1, x2, w, cfg, has_b, out=gview)
+                    else:   # thin-input / thin-output kernels return their own tensor: copied into the slot
+                        dw_, db_ = conv_wgrad(dz, x1, x2, w, cfg, has_b)
+                        gview.copy_(dw_)
+                    owner.grad_written(param)
+                    return db_
                 side = owner.wgrad_stream() if (dz.is_cuda and hasattr(owner, "wgrad_stream")) else None
                 if side is not None and has_b:
                     # the bias gradient comes back as a tensor: safe on the side stream only if autograd hands it over
@@ -599,14 +608,12 @@ class _FusedConv(torch.autograd.Function):
                     owner.note_side_launch(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
                         side.wait_event(ready)
-                        _, db = conv_wgrad(dz, x1, x2, w, cfg, has_b, out=gview)
-                        owner.grad_written(param)
+                        db = run_wgrad()
                     for t in (dz, x1, x2):
                         if t is not None:
                             t.record_stream(side)     # their memory is not recycled before the side stream is done
                 else:
-                    _, db = conv_wgrad(dz, x1, x2, w, cfg, has_b, out=gview)
-                    owner.grad_written(param)
+                    db = run_wgrad()
             else:
                 if _direct_grad and need[2]:
                     ent = _direct_entry(w)
