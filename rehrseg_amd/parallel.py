@@ -27,9 +27,9 @@ Weight gradients on a second HIP stream (`wgrad_stream=True`, default on the dev
 the weight gradient does not feed the chain to the layer below -- only the input gradient does.  The direct-route
 weight-gradient kernels are therefore launched on a side stream (after an event that marks dz complete) while the main
 stream goes on with the input gradient and the HBM-bound InstanceNorm / SEGating passes of the next layer down: the
-matrix-core kernel of one stream fills the tail rounds and the memory-bound passes of the other (cfg-3: 47.6 -> 43.3 ms
-per step, cfg-2: 61.6 -> 60.2, tools/exp_side_stream.py).  Nothing reads a side-stream result before the join in
-`reduce_gradients()`: the kernels write into the flat buffer (no autograd accumulation), bias gradients are handed over
+matrix-core kernel of one stream fills the tail rounds and the memory-bound passes of the other (cfg-3: 48.2 -> 45.5 ms per step, cfg-2: 61.4 -> 60.3, cfg-4: 43.6 -> 40.0).  Nothing reads a side-stream
+result before the join, which the first side launch of a backward pass queues as an end-of-backward callback of the
+autograd engine (and `reduce_gradients()` repeats): the kernels write into the flat buffer (no autograd accumulation), bias gradients are handed over
 to parameters whose `.grad` is None, and a bucket's all-reduce launched from the side stream first waits for the main
 one.  Same kernels, same operands, same results.
 """
@@ -91,6 +91,7 @@ class PatchParallel:
         self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._side = self._side_stream if wgrad_stream else None
         self._side_used = False
+        self._join_queued = False
         self._main = None
         self._reset_step()
         if self.overlap:
@@ -147,9 +148,22 @@ class PatchParallel:
         self._side = self._side_stream if enabled else None
 
     def note_side_launch(self, main_stream):
-        """A kernel is about to be launched on the side stream; `main_stream` is the stream the backward runs on."""
+        """A kernel is about to be launched on the side stream (called from inside a backward function);
+        `main_stream` is the stream the backward runs on.  The first launch of a backward pass queues the join as an
+        end-of-backward callback of the autograd engine: whoever reads a gradient on the main stream after
+        `backward()` returns -- `reduce_gradients()`, an optimizer, a test -- sees completed kernels."""
         self._side_used = True
         self._main = main_stream
+        if not self._join_queued:
+            self._join_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self):
+        self._join_queued = False
+        if self._side is not None and self._side_used and self._main is not None:
+            self._main.wait_stream(self._side)
+            # (buckets still to be launched from reduce_gradients() run on the main stream, which is now behind the
+            # side stream; _side_used stays set so that an exchange launched later in this step keeps its ordering)
 
     def join_side(self):
         """Public form of the join: called before a gradient that a side-stream kernel may still be writing is touched

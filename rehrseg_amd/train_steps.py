@@ -17,10 +17,12 @@ import torch.nn.functional as F
 from .utils.seg_utils import zscore_normalization
 
 
-def get_intermediate_features(model_sr, img_lr, label_lr, device=None, levels=None):
+def get_intermediate_features(model_sr, img_lr, label_lr, device=None, levels=None, _normalized=None):
     """dict level -> (B, C_level, D, h, w).  Like the reference it z-scores `img_lr` IN PLACE
-    (the student is fed the normalised image afterwards, train_all.py:533-534)."""
-    img_lr = zscore_normalization(img_lr)
+    (the student is fed the normalised image afterwards, train_all.py:533-534).
+    _normalized: the result of zscore_normalization(img_lr) when the caller has already applied it (train_segsr_step
+    normalises on the main stream and runs the rest of the teacher pass on a second one)."""
+    img_lr = zscore_normalization(img_lr) if _normalized is None else _normalized
     x = torch.cat((img_lr, label_lr), dim=1)                     # (B, 2, D, H, W)
     B, C, D, H, W = x.shape
     if D < 2:
@@ -94,14 +96,48 @@ def train_sr_step(model, opt, scheduler, patches_lr, patches_hr, loss_obj, loss_
     return loss
 
 
+_TEACHER_STREAMS = {}
+
+
+def _teacher_stream(t):
+    """One extra HIP stream per device for the teacher pass of train_segsr_step (None for CPU tensors: host-logic tests)."""
+    if not t.is_cuda:
+        return None
+    key = t.device.index
+    if key not in _TEACHER_STREAMS:
+        _TEACHER_STREAMS[key] = torch.cuda.Stream(device=t.device)
+    return _TEACHER_STREAMS[key]
+
+
 def train_segsr_step(model_seg, model_sr, distiller, opt, img, label_lr, label_hr, uncertainty_lr, loss_lr_seg,
-                     loss_hr_seg, enable_uncertainty=True, teacher_levels=(1,), grad_sync=None, zero_grad=None):
-    """One iteration of the stage-2 loop (train_all.py:521-556); returns the loss tensor."""
+                     loss_hr_seg, enable_uncertainty=True, teacher_levels=(1,), grad_sync=None, zero_grad=None,
+                     teacher_stream=True):
+    """One iteration of the stage-2 loop (train_all.py:521-556); returns the loss tensor.
+    teacher_stream: run the frozen teacher's pass on a second HIP stream next to the student's forward."""
     model_seg.train()
     if distiller is not None:
-        with torch.no_grad():
-            features_sr = get_intermediate_features(model_sr, img, label_lr, img.device, levels=teacher_levels)
-        seg_lr, seg_sr, features_seg = model_seg(img, return_inetermediate_feature=True)
+        side = _teacher_stream(img) if teacher_stream else None
+        if side is None:
+            with torch.no_grad():
+                features_sr = get_intermediate_features(model_sr, img, label_lr, img.device, levels=teacher_levels)
+            seg_lr, seg_sr, features_seg = model_seg(img, return_inetermediate_feature=True)
+        else:
+            # The frozen teacher's pass and the student's forward are independent once the image is z-scored (in place,
+            # as the reference does: the student reads the normalised image): the teacher runs on a second HIP stream,
+            # the student on the current one, joined before the distillation loss.  Same kernels, same results.
+            main = torch.cuda.current_stream(img.device)
+            with torch.no_grad():
+                normalized = zscore_normalization(img)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                features_sr = get_intermediate_features(model_sr, img, label_lr, img.device, levels=teacher_levels,
+                                                        _normalized=normalized)
+            seg_lr, seg_sr, features_seg = model_seg(img, return_inetermediate_feature=True)
+            main.wait_stream(side)
+            for t in features_sr.values():
+                t.record_stream(main)          # allocated on the side stream, consumed (and later freed) on the main one
+            for t in (img, label_lr, normalized):
+                t.record_stream(side)
     else:
         seg_lr, seg_sr = model_seg(img)
     if enable_uncertainty:
