@@ -129,7 +129,8 @@ def _same_dtype(*ts):
 # Small zero-initialised fp64 accumulators (per-(sample, channel) statistics, gradient reductions): every fused layer
 # needs one or two per pass, and a torch.zeros() each is a 5 us fill launch -- ~90 per cfg-2 step.  They are carved out
 # of a pooled chunk that is zeroed by ONE fill when it is allocated; a slice is handed out once and never reused (the
-# chunk lives as long as any slice of it does), so no kernel ever sees stale values.
+# chunk lives as long as any slice of it does), so no kernel ever sees stale values.  One pool per (device, stream): the
+# fill runs on the stream that is current when the chunk is made, and only kernels of that stream may rely on it.
 _zero_pool = {}
 _ZERO_CHUNK = 1 << 16   # doubles (512 KB)
 
@@ -141,7 +142,7 @@ def zeros_f64(shape, device):
     n_al = (n + 1) & ~1                                   # keep 16-byte alignment of every slice
     if n_al > _ZERO_CHUNK // 4:
         return torch.zeros(shape, dtype=torch.float64, device=device)
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     ent = _zero_pool.get(key)
     if ent is None or ent[1] + n_al > _ZERO_CHUNK:
         ent = [torch.zeros(_ZERO_CHUNK, dtype=torch.float64, device=device), 0]
