@@ -138,6 +138,9 @@ def main():
                     help="weight gradients on the main stream (default: PatchParallel launches them on a second HIP stream); "
                          "the per-kernel pass always runs without it, and the rocprofv3 kernel statistics under profiles/ "
                          "are collected with this flag so that kernel durations are not inflated by a co-running kernel")
+    ap.add_argument("--no-teacher-stream", action="store_true",
+                    help="cfg4 / cfg5: the frozen teacher's pass on the main stream (default: a second HIP stream, next to "
+                         "the student's forward)")
     ap.add_argument("--kernel-steps", type=int, default=0,
                     help="steps of the separate per-kernel timing pass (0: max(--steps, 50), at most 100)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -279,7 +282,7 @@ def main():
 
         def step():
             return train_segsr_step(student, teacher, dist_m, opt, img.clone(), lab_lr, lab_hr, unc, l_lr, l_hr,
-                                    grad_sync=pp.reduce_gradients)
+                                    grad_sync=pp.reduce_gradients, teacher_stream=not args.no_teacher_stream)
     else:
         model = build_seg_model(dev)
         pp = PatchParallel(model, wgrad_stream=not args.no_wgrad_stream)
