@@ -185,6 +185,7 @@ def main():
     from rehrseg_amd import ops
     size = args.size
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # every rank draws its own patch
+    streams = {"teacher": not args.no_teacher_stream}     # (the per-kernel pass switches the second streams off)
     if args.workload == "stub":
         # plumbing only (tests): a two-layer torch Conv3d net, no HIP kernels; exercises the launch, the flat-bucket
         # exchange and the report with CPU ranks
@@ -282,7 +283,7 @@ def main():
 
         def step():
             return train_segsr_step(student, teacher, dist_m, opt, img.clone(), lab_lr, lab_hr, unc, l_lr, l_hr,
-                                    grad_sync=pp.reduce_gradients, teacher_stream=not args.no_teacher_stream)
+                                    grad_sync=pp.reduce_gradients, teacher_stream=streams["teacher"])
     else:
         model = build_seg_model(dev)
         pp = PatchParallel(model, wgrad_stream=not args.no_wgrad_stream)
@@ -381,6 +382,7 @@ def main():
     if not args.no_kernel_timing and not on_cpu:
         ksteps = args.kernel_steps or min(100, max(args.steps, 50))
         pp.set_wgrad_stream(False)                  # one kernel at a time on the chip: un-shared durations
+        streams["teacher"] = False
         for _ in range(2):
             step()                                  # the GPU idled through the CPU leg
         torch.cuda.synchronize()

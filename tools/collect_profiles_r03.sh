@@ -4,6 +4,9 @@
 R=$PWD; O=$R/gpurun_out/r3p; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 PART=${1:-all}
 B="--no-cpu-baseline"
+# per-kernel evidence (stats, PMC) is collected with the second HIP streams off: a kernel that shares the chip with
+# another stream's kernel has neither its own duration nor its own counters
+S="--no-wgrad-stream --no-teacher-stream"
 prof() { timeout -k 10 300 rocprofv3 "$@"; }
 if [ "$PART" = all ] || [ "$PART" = bench ]; then   # the bench lines of every workload, un-profiled, on this one box
 python3 $R/bench.py > $O/b_flavr_fp32.log 2>&1 || exit 1; tail -1 $O/b_flavr_fp32.log > $O/b_flavr_fp32.json
@@ -19,21 +22,22 @@ for w in flavr_ref flavr seg; do python3 $R/tools/layer_times.py $w > $O/layers_
 fi
 if [ "$PART" = all ] || [ "$PART" = stats ]; then
 for w in flavr seg cfg4 flavr_ref; do
-  prof --kernel-trace --stats --output-format csv -d $O/k_$w -o k -- python3 $R/bench.py --workload $w --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_$w.log 2>&1 || exit 1
+  prof --kernel-trace --stats --output-format csv -d $O/k_$w -o k -- python3 $R/bench.py --workload $w --steps 5 --warmup 2 $B $S --no-kernel-timing > $O/k_$w.log 2>&1 || exit 1
 done
-prof --kernel-trace --stats --output-format csv -d $O/k_seg_bf16 -o k -- python3 $R/bench.py --workload seg --precision bf16 --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_seg_bf16.log 2>&1 || exit 1
-prof --kernel-trace --stats --output-format csv -d $O/k_cfg5 -o k -- python3 $R/bench.py --workload cfg5 --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_cfg5.log 2>&1 || exit 1
-prof --kernel-trace --stats --output-format csv -d $O/k_flavr_bf16 -o k -- python3 $R/bench.py --workload flavr --precision bf16 --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_flavr_bf16.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_seg_bf16 -o k -- python3 $R/bench.py --workload seg --precision bf16 --steps 5 --warmup 2 $B $S --no-kernel-timing > $O/k_seg_bf16.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_cfg5 -o k -- python3 $R/bench.py --workload cfg5 --steps 5 --warmup 2 $B $S --no-kernel-timing > $O/k_cfg5.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_flavr_overlap -o k -- python3 $R/bench.py --workload flavr --steps 5 --warmup 2 $B --no-kernel-timing > $O/k_flavr_overlap.log 2>&1 || exit 1
+prof --kernel-trace --stats --output-format csv -d $O/k_flavr_bf16 -o k -- python3 $R/bench.py --workload flavr --precision bf16 --steps 5 --warmup 2 $B $S --no-kernel-timing > $O/k_flavr_bf16.log 2>&1 || exit 1
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 for w in flavr seg cfg5; do
-  prof --kernel-trace --output-format csv -d $O/t_$w -o t -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/t_$w.log 2>&1 || exit 1
-  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f_$w -o f -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/f_$w.log 2>&1 || exit 1
-  prof --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w_$w -o w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/w_$w.log 2>&1 || exit 1
-  prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_$w -o m -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_$w.log 2>&1 || exit 1
+  prof --kernel-trace --output-format csv -d $O/t_$w -o t -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B $S --no-kernel-timing > $O/t_$w.log 2>&1 || exit 1
+  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f_$w -o f -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B $S --no-kernel-timing > $O/f_$w.log 2>&1 || exit 1
+  prof --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w_$w -o w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B $S --no-kernel-timing > $O/w_$w.log 2>&1 || exit 1
+  prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_$w -o m -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 $B $S --no-kernel-timing > $O/m_$w.log 2>&1 || exit 1
 done
-prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_flavr_ref -o m -- python3 $R/bench.py --workload flavr_ref --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_flavr_ref.log 2>&1 || exit 1
-prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_seg_bf16 -o m -- python3 $R/bench.py --workload seg --precision bf16 --steps 2 --warmup 1 $B --no-kernel-timing > $O/m_seg_bf16.log 2>&1 || exit 1
+prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_flavr_ref -o m -- python3 $R/bench.py --workload flavr_ref --steps 2 --warmup 1 $B $S --no-kernel-timing > $O/m_flavr_ref.log 2>&1 || exit 1
+prof --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/m_seg_bf16 -o m -- python3 $R/bench.py --workload seg --precision bf16 --steps 2 --warmup 1 $B $S --no-kernel-timing > $O/m_seg_bf16.log 2>&1 || exit 1
 fi
 if [ "$PART" = all ] || [ "$PART" = stream ]; then
 prof --kernel-trace --output-format csv -d $O/t_stream -o t -- python3 $R/tools/bench_stream.py --json $O/stream_algo.json > $O/t_stream.log 2>&1 || exit 1

@@ -1,7 +1,7 @@
 # gpurun_out/r3p (scratch, written by tools/collect_profiles_r03.sh on the GPU box) -> profiles/r03_* (tracked).
 # Run in the build container from the repo root after the gpurun call has merged its outputs.
 O=gpurun_out/r3p; P=profiles
-for w in flavr seg cfg4 flavr_ref seg_bf16 cfg5 flavr_bf16; do
+for w in flavr seg cfg4 flavr_ref seg_bf16 cfg5 flavr_bf16 flavr_overlap; do
   [ -f $O/k_$w/k_kernel_stats.csv ] && cp $O/k_$w/k_kernel_stats.csv $P/r03_${w}_kernel_stats.csv
 done
 for f in $O/b_*.json; do
