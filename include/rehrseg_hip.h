@@ -106,6 +106,17 @@ typedef struct {
 
 /* bf16 entry points: store y as fp32 instead of bf16 (logits, features handed to fp32 losses) */
 #define REHR_GG_Y_F32 1
+/* fp32 entry points, wino_ws given.  The Winograd-domain weights in wino_ws depend on wp and on the descriptor's
+ * geometry only, so a caller whose weights have not changed since an earlier call with the same geometry may keep the
+ * scratch and skip the transform launch:
+ *   REHR_GG_WS_ONLY   run ONLY the weight transform(s) this descriptor (or this multi-call) would run: wino_ws is
+ *                     filled, nothing else is launched, x1 / x2 / y / bias / stats are not dereferenced (REHR_OK also
+ *                     when no Winograd kernel takes the descriptor: nothing to prepare);
+ *   REHR_GG_WS_READY  wino_ws already holds what REHR_GG_WS_ONLY (or a full call) with the same geometry, the same wp
+ *                     contents and the same debug_flags wrote: skip the transform.
+ * In a multi-call every descriptor carries the same two bits. */
+#define REHR_GG_WS_READY 2
+#define REHR_GG_WS_ONLY 4
 
 /* debug_flags (unstable; the parity tests compare kernel organisations with each other through them):
  * bf16: never take the LDS halo-brick kernel (per-tap gather kernel instead) */

@@ -598,7 +598,7 @@ inline int64_t rows_per_block_for(int64_t S, int C, int N) {
 #define ST ((hipStream_t)stream)
 
 thread_local int rehr_last_hip_error_code = 0;
-extern "C" int rehr_abi_version(void) { return 3; }
+extern "C" int rehr_abi_version(void) { return 4; }
 extern "C" const char* rehr_last_hip_error(void) {
   return hipGetErrorString((hipError_t)rehr_last_hip_error_code);
 }

@@ -498,7 +498,12 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
       return REHR_EINVAL;  // (y may differ: split-K partials go to separate slabs)
   }
   hipStream_t st = (hipStream_t)stream;
-  if (count > 1) {   // the stride phases of a kernel == stride transposed convolution: one fused launch
+  // REHR_GG_WS_ONLY: the weight transforms of this call and nothing else (every Winograd try-function below returns
+  // right behind its transform launch; whatever no Winograd kernel takes has nothing to prepare)
+  const bool ws_only = (descs[0].flags & REHR_GG_WS_ONLY) != 0;
+  for (int i = 1; i < count; ++i)
+    if ((descs[i].flags ^ descs[0].flags) & (REHR_GG_WS_ONLY | REHR_GG_WS_READY)) return REHR_EINVAL;
+  if (count > 1 && !ws_only) {   // the stride phases of a kernel == stride transposed convolution: one fused launch
     const int trc = tconv_ks_try(descs, count, false, st);
     if (trc != REHR_ENOSUP) return trc;
   }
@@ -529,6 +534,7 @@ extern "C" int rehr_gather_gemm_multi_f32(const rehr_gather_gemm_desc* descs, in
       if (wrc == REHR_OK) continue;
       if (wrc != REHR_ENOSUP) return wrc;
     }
+    if (ws_only) continue;
     if (descs[i].tile_d >= 0) {  // the halo-tile kernel takes what it is good at, one launch each
       const int hrc = halo_conv_try(descs[i], st);
       if (hrc == REHR_OK) continue;

@@ -736,7 +736,11 @@ static int wino22_flat_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   const int64_t total = (int64_t)p.nphase * d.td.count * d.Npad * p.kchunks * 32;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, p.kchunks);
+  if (!(d.flags & REHR_GG_WS_READY)) {
+    hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, p.kchunks);
+    REHR_LAUNCH_CHECK();
+  }
+  if (d.flags & REHR_GG_WS_ONLY) return REHR_OK;
   const size_t smem = (size_t)(p.tab_off + 3 * 64) * sizeof(float);
   if (!f22_allow_smem(smem)) return REHR_EHIP;
   dim3 grid((unsigned)((p.ntiles + 63) / 64), d.Npad / 64, 1);
@@ -778,7 +782,12 @@ int wino22_flat_multi_try(const rehr_gather_gemm_desc* ds, int count, hipStream_
     const int64_t total = (int64_t)ds[i].td.count * ds[i].Npad * p.kchunks * 32;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ds[i], ds[i].wino_ws, p.kchunks);
+    if (!(ds[i].flags & REHR_GG_WS_READY))
+      hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ds[i], ds[i].wino_ws, p.kchunks);
+  }
+  if (d0.flags & REHR_GG_WS_ONLY) {
+    REHR_LAUNCH_CHECK();
+    return REHR_OK;
   }
   const size_t smem = (size_t)(p.tab_off + 3 * 64) * sizeof(float);
   if (!f22_allow_smem(smem)) return REHR_EHIP;
@@ -800,7 +809,11 @@ int wino22_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   const int64_t total = (int64_t)p.nphase * d.td.count * d.Npad * p.kchunks * 32;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, p.kchunks);
+  if (!(d.flags & REHR_GG_WS_READY)) {
+    hipLaunchKernelGGL(w22_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws, p.kchunks);
+    REHR_LAUNCH_CHECK();
+  }
+  if (d.flags & REHR_GG_WS_ONLY) return REHR_OK;
   const size_t smem_x = (size_t)2 * BUF * sizeof(float), smem_e = (size_t)4 * 3 * 2 * 16 * 64 * sizeof(float);
   const size_t smem = smem_x > smem_e ? smem_x : smem_e;
   static bool attr_set = false;

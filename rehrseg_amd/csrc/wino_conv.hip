@@ -1023,6 +1023,7 @@ bool big_ok(const rehr_gather_gemm_desc& d) {
 
 // fragment-ordered weight transform, shared with wino_flat8_conv.hip
 int wino_weights_frag_launch(const rehr_gather_gemm_desc& d, int kchunks, hipStream_t stream) {
+  if (d.flags & REHR_GG_WS_READY) return REHR_OK;   // the caller kept the transformed weights of an earlier call
   const int64_t total = (int64_t)d.td.count * d.Npad * kchunks * 32;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -1089,6 +1090,7 @@ int wino_conv_split_try(const rehr_gather_gemm_desc* ds, int count, hipStream_t 
     const int rc = wino_weights_frag_launch(ds[i], p.kchunks, stream);
     if (rc != REHR_OK) return rc;
   }
+  if (d0.flags & REHR_GG_WS_ONLY) return REHR_OK;
   p.nb_h = (d0.Lh + 15) / 16;
   p.nb_w = (d0.Lw + 15) / 16;
   const size_t smem_x = (size_t)2 * BUF2 * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
@@ -1117,11 +1119,8 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   p.nsplit = 0;
   p.band_major = (d.debug_flags & REHR_DBG_GG_SLICE_MAJOR) ? 0 : 1;
   if (w32_ok(d)) {
-    const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wino_weights_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws,
-                       p.kchunks);
+    const int wrc = wino_weights_frag_launch(d, p.kchunks, stream);
+    if (wrc != REHR_OK || (d.flags & REHR_GG_WS_ONLY)) return wrc;
     const int nfm = w32_groups(d);
     p.nb_h = (d.Lh + 8 * nfm - 1) / (8 * nfm);
     p.nb_w = (d.Lw + 15) / 16;
@@ -1136,11 +1135,8 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
     return REHR_OK;
   }
   if (big_ok(d)) {
-    const int64_t total = (int64_t)d.td.count * d.Npad * p.kchunks * 32;
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wino_weights_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws,
-                       p.kchunks);
+    const int wrc = wino_weights_frag_launch(d, p.kchunks, stream);
+    if (wrc != REHR_OK || (d.flags & REHR_GG_WS_ONLY)) return wrc;
     p.nb_h = (d.Lh + 15) / 16;
     p.nb_w = (d.Lw + 15) / 16;
     const size_t smem_x = (size_t)2 * BUF2 * sizeof(float), smem_e = (size_t)4 * 4 * 2 * 16 * 64 * sizeof(float);
@@ -1160,12 +1156,14 @@ int wino_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   const int64_t nb_h = (d.Lh + 2 * TH - 1) / (2 * TH), nb_w = (d.Lw + 2 * TW - 1) / (2 * TW);
 
   // weight transform (reads the packed panel, writes the workspace)
-  {
+  if (!(d.flags & REHR_GG_WS_READY)) {
     const int64_t total = (int64_t)d.td.count * d.Npad * d.Cin;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, d.wino_ws);
+    REHR_LAUNCH_CHECK();
   }
+  if (d.flags & REHR_GG_WS_ONLY) return REHR_OK;
   p.nb_h = (int)nb_h;
   p.nb_w = (int)nb_w;
   const size_t smem_x = (size_t)2 * PVOX * LDX * sizeof(float), smem_e = (size_t)4 * 2 * 16 * 64 * sizeof(float);

@@ -487,7 +487,7 @@ int wino_flat8_conv_try(const rehr_gather_gemm_desc& d, hipStream_t stream) {
   Flat8Params& q = nfm == 1 ? p1 : p;
   q.up = d.wino_ws;
   int rc = wino_weights_frag_launch(d, q.kchunks, stream);
-  if (rc != REHR_OK) return rc;
+  if (rc != REHR_OK || (d.flags & REHR_GG_WS_ONLY)) return rc;
   rc = nfm == 1 ? launch_flat8<1>(q, stream) : launch_flat8<2>(q, stream);
   if (rc != REHR_OK) return rc;
   REHR_LAUNCH_CHECK();

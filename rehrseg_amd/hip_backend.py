@@ -10,8 +10,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 import functools
+import weakref
 
 import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
 
 from . import lib as L
 
@@ -159,20 +161,181 @@ def new_act(N, Cc, D, H, W, like, zero=False, dtype=None):
     return t.zero_() if zero else t
 
 
-def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32):
-    """fp32 master weights in the torch parameter layout -> kernel panel [T][Apad][B] in `dtype` (fp32 / bf16)."""
-    _chk_dev(w)
-    w = w.contiguous()
-    if w.dtype != torch.float32:
-        raise L.RehrsegHipError("master weights are float32")
-    out = torch.empty((T, Apad, B), dtype=dtype, device=w.device)
-    if dtype == torch.bfloat16:
-        L.check(L.load().rehr_pack_weights_bf16(_ptr(w), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
+# ---- weight forms kept across launches ----------------------------------------------------------------------------
+# A convolution needs its weights as a kernel panel (pack_weights) and, on the fp32 Winograd kernels, as
+# transform-domain fragments (the library's weight-transform launch into `wino_ws`): two 5-20 us launches of a few
+# blocks each in front of every forward and every input-gradient kernel, 95 per cfg-2 step = 1.5 ms of a mostly idle
+# chip.  Both depend on the parameter's VALUES and the layer geometry only, so they are kept per (parameter, geometry)
+# and rebuilt when the parameter has changed: its version counter has moved (load_state_dict, any in-place torch op) or
+# an optimizer has stepped over it (torch's fused optimizers do NOT move version counters, so a global
+# optimizer-step post hook stamps the parameters of every optimizer that steps).  A write through `.data` is seen by
+# neither, by torch's design: call invalidate_weight_forms() after one.  The first request that meets a stale form rebuilds ALL stale forms, in the order they were first asked
+# for, on a second stream next to the forward's first kernels; a consumer waits for its form's event.  Frozen
+# networks (the joint step's teacher, inference) keep their forms for good.
+WEIGHT_FORM_CACHE = True     # False: every call packs / transforms on its own stream (tests compare the two)
+WEIGHT_FORM_STREAM = True    # False: stale forms are rebuilt one by one where they are needed, on the caller's stream
+
+
+def _after_optimizer_step(opt, args, kwargs):
+    for g in opt.param_groups:
+        for p in g["params"]:
+            p._rehr_stamp = getattr(p, "_rehr_stamp", 0) + 1
+
+
+_register_step_hook(_after_optimizer_step)
+
+
+def _ver(p):
+    """What a form remembers of the parameter it was made from."""
+    return (p._version, getattr(p, "_rehr_stamp", 0))
+
+
+class _Form:
+    __slots__ = ("param", "version", "out", "make", "event", "made_on", "seen_by", "dep", "ticket", "__weakref__")
+
+    def __init__(self, key, param, make, dep=None):
+        self.param = weakref.ref(param, lambda _r, k=key: _drop_form(k))   # the forms go when the parameter goes
+        self.version = None          # parameter version `out` was made from
+        self.out = None              # pack: the panel tensor; Winograd: list of scratch tensors (one per descriptor)
+        self.make = make             # make(parameter): launches the rebuild on the current stream
+        self.event = None
+        self.made_on = None          # stream handle the last rebuild ran on
+        self.seen_by = set()         # stream handles that are ordered behind that rebuild
+        self.dep = dep               # Winograd forms: the pack form they read
+        self.ticket = 0              # number of the batch rebuild that made it (0: made in place)
+
+
+_forms = {}                # key -> _Form, in first-request order
+_form_of_panel = {}        # id(panel tensor) -> pack form (Winograd forms find the parameter behind a `wp`)
+_form_streams = {}         # device index -> side stream
+_form_batch = {"ticket": 0, "done": None, "count": 0, "used": 0, "joined": True}
+form_rebuilds = 0          # launches issued for rebuilding forms (tests look at this)
+
+
+def _drop_form(key):
+    f = _forms.pop(key, None)
+    if f is not None and key[0] == "pack":
+        _form_of_panel.pop(id(f.out), None)
+
+
+def invalidate_weight_forms():
+    """Forget every kept weight form (after writing parameters through `.data`, which no version counter sees)."""
+    join_weight_forms()
+    _forms.clear()
+    _form_of_panel.clear()
+
+
+def join_weight_forms():
+    """The current stream waits for the last batch rebuild (before parameters are overwritten by something torch's
+    stream order does not already put behind every consumer of the forms; PatchParallel.reduce_gradients calls it)."""
+    b = _form_batch
+    if not b["joined"] and b["done"] is not None:
+        torch.cuda.current_stream().wait_event(b["done"])
+        b["joined"] = True
+
+
+def _form_ready(f, p):
+    """Make form `f` of parameter `p` current and order the current stream behind its rebuild."""
+    cur = torch.cuda.current_stream(p.device)
+    if f.version != _ver(p) or (f.dep is not None and f.dep.version != _ver(p)):
+        if WEIGHT_FORM_STREAM and f.version is not None and not _form_batch.get("running"):
+            _rebuild_stale(p.device, cur)
+        if f.version != _ver(p):                    # first sight (or the batch did not reach it): in place
+            if f.dep is not None:
+                _form_ready(f.dep, p)
+            if f.event is not None and f.made_on != cur.cuda_stream:
+                cur.wait_event(f.event)                 # an older rebuild on another stream may still be writing
+            _make(f, p, cur, 0)
+    h = cur.cuda_stream
+    if f.made_on != h and h not in f.seen_by:
+        cur.wait_event(f.event)
+        f.seen_by.add(h)
+    b = _form_batch
+    if f.ticket and f.ticket == b["ticket"] and not b["joined"]:
+        # the whole batch is joined once a quarter of it has been consumed: long before that the side stream has
+        # drained, and from then on the next optimizer step is ordered behind every read of the parameters
+        b["used"] += 1
+        if b["used"] * 4 >= b["count"]:
+            cur.wait_event(b["done"])
+            b["joined"] = True
+
+
+def _make(f, p, stream, ticket):
+    global form_rebuilds
+    f.make(p)
+    form_rebuilds += 1
+    f.version = _ver(p)
+    if f.event is None:
+        f.event = torch.cuda.Event()
+    f.event.record(stream)
+    f.made_on = stream.cuda_stream
+    f.seen_by = set()
+    f.ticket = ticket
+
+
+def _rebuild_stale(device, cur):
+    """All stale forms of parameters on `device`, in first-request order, on the side stream."""
+    side = _form_streams.get(device.index)
+    if side is None:
+        side = _form_streams[device.index] = torch.cuda.Stream(device=device)
+    b = _form_batch
+    join_weight_forms()                                 # (an unjoined older batch: finish it first)
+    side.wait_stream(cur)                               # behind the update of the parameters, behind every old reader
+    b["running"] = True
+    n = 0
+    try:
+        with torch.cuda.stream(side):
+            tk = b["ticket"] + 1
+            for k in list(_forms):
+                f = _forms.get(k)
+                p = f.param() if f is not None else None
+                if p is None or p.device != device or f.version is None:
+                    continue
+                if f.version != _ver(p) and (f.dep is None or f.dep.version == _ver(p)):
+                    _make(f, p, side, tk)
+                    n += 1
+            if n:
+                if b["done"] is None:
+                    b["done"] = torch.cuda.Event()
+                b["done"].record(side)
+                b.update(ticket=tk, count=n, used=0, joined=False)
+    finally:
+        b["running"] = False
+
+
+def _pack_launch(src, out, A, Apad, B, T, transpose):
+    if out.dtype == torch.bfloat16:
+        L.check(L.load().rehr_pack_weights_bf16(_ptr(src), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
                 "rehr_pack_weights_bf16")
     else:
-        L.check(L.load().rehr_pack_weights_f32(_ptr(w), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
+        L.check(L.load().rehr_pack_weights_f32(_ptr(src), _ptr(out), A, Apad, B, T, int(transpose), _stream()),
                 "rehr_pack_weights_f32")
-    return out
+
+
+def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32, part=None):
+    """fp32 master weights in the torch parameter layout -> kernel panel [T][Apad][B] in `dtype` (fp32 / bf16).
+    `part` = (dim, lo, count): the panel of w.narrow(dim, lo, count) (the halves of a virtual channel concat).
+    Panels of nn.Parameters are kept until the parameter changes (see "weight forms" above)."""
+    _chk_dev(w)
+    if w.dtype != torch.float32:
+        raise L.RehrsegHipError("master weights are float32")
+
+    def src(p):
+        return (p if part is None else p.narrow(*part)).contiguous()
+
+    if not (WEIGHT_FORM_CACHE and isinstance(w, torch.nn.Parameter)):
+        out = torch.empty((T, Apad, B), dtype=dtype, device=w.device)
+        _pack_launch(src(w), out, A, Apad, B, T, transpose)
+        return out
+    key = ("pack", id(w), tuple(w.shape), part, A, Apad, B, T, bool(transpose), dtype)
+    f = _forms.get(key)
+    if f is None or f.param() is not w:
+        out = torch.empty((T, Apad, B), dtype=dtype, device=w.device)
+        f = _forms[key] = _Form(key, w, lambda p: _pack_launch(src(p), out, A, Apad, B, T, transpose))
+        f.out = out
+        _form_of_panel[id(out)] = f
+    _form_ready(f, w)
+    return f.out
 
 
 # Kernel selection travels in the descriptors (the library reads no environment).  With `flags` / `debug_flags` = 0
@@ -220,7 +383,7 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
     d.wino_ws, d.wino_ws_bytes = None, 0
     d.flags = 0
     d.debug_flags = 0
-    keep = None
+    need = 0
     if x1.dtype == torch.bfloat16:
         if wp.dtype != torch.bfloat16 or (x2 is not None and x2.dtype != torch.bfloat16):
             raise L.RehrsegHipError("mixed-precision gather-GEMM: x1, x2 and the packed weights must all be bfloat16")
@@ -234,21 +397,60 @@ def _gg_desc(d, x1, x2, c1, src_dims, Cin, lattice, s, b, taps, KH, KW, wp, Npad
         d.debug_flags = ((0 if USE_WINO_FLAT8 else L.DBG_GG_NO_FLAT8) |
                          {1: L.DBG_GG_W32P_TWO_PER_CU, 2: L.DBG_GG_W32P_ONE_PER_CU}.get(W32P_BLOCKS, 0) |
                          {1: L.DBG_GG_FLAT8_HALF, 2: L.DBG_GG_FLAT8_FULL}.get(WINO_FLAT8_TILES, 0))
-        nbytes = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
-        if nbytes > 0:
-            keep = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
-            global wino_launches
-            wino_launches += 1
-            d.wino_ws, d.wino_ws_bytes = _ptr(keep), nbytes
+        need = L.load().rehr_gather_gemm_wino_bytes(C.byref(d))
     if PHASE_INTERLEAVE:
         d.debug_flags |= L.DBG_GG_INTERLEAVE
     if not USE_TCONV_KS:
         d.debug_flags |= L.DBG_GG_NO_TCONV_KS
     if not WINO_BAND_MAJOR:
         d.debug_flags |= L.DBG_GG_SLICE_MAJOR
-    d._keep = keep  # scratch stays referenced until the launch has been enqueued
-    _gg_desc.last_keep = keep  # (an element of a ctypes array is a temporary wrapper: the caller holds this one)
+    # (the Winograd scratch is attached by _attach_ws once every descriptor of the call is known)
+    _gg_desc.need = need
+    _gg_desc.sig = (c1, x1.shape[1], x2.shape[1] if x2 is not None else 0, x1.shape[0], tuple(src_dims), Cin,
+                    tuple(lattice), tuple(s), tuple(b), tuple(tuple(t) for t in taps), KH, KW, Npad, tuple(y_dims), Cout,
+                    y.shape[1], tuple(os_), tuple(ob), bias is not None, act, stats_mode, tuple(tile), d.debug_flags)
     return _algo_flops(d.N, lattice, s, b, taps, src_dims, Cin, Cout) if _prof is not None else 0.0
+
+
+def _attach_ws(descs, n, needs, sigs, wp):
+    """Winograd scratch for the descriptors of one call that want it.  Returns what must stay referenced until the
+    launch has been enqueued.  When `wp` is the kept panel of a parameter the transformed weights are kept too (one form
+    per call geometry) and the call runs with REHR_GG_WS_READY."""
+    if not any(needs):
+        return None
+    global wino_launches
+    wino_launches += sum(1 for nb in needs if nb)
+    dev = wp.device
+    pf = _form_of_panel.get(id(wp)) if WEIGHT_FORM_CACHE else None
+    p = pf.param() if pf is not None else None
+    if p is None:
+        keeps = [torch.empty(nb // 4, dtype=torch.float32, device=dev) if nb else None for nb in needs]
+        for i in range(n):
+            if needs[i]:
+                descs[i].wino_ws, descs[i].wino_ws_bytes = _ptr(keeps[i]), needs[i]
+        return keeps
+    key = ("ws", id(p), id(pf), tuple(sigs))
+    f = _forms.get(key)
+    if f is None or f.param() is not p or f.dep is not pf:
+        outs = [torch.empty(nb // 4, dtype=torch.float32, device=dev) if nb else None for nb in needs]
+        cp = (L.GatherGemmDesc * n)()       # the rebuild call: the same descriptors, transforms only (operand pointers
+        for i in range(n):                  # other than wp / wino_ws go stale and are not dereferenced)
+            C.memmove(C.byref(cp[i]), C.byref(descs[i]), C.sizeof(L.GatherGemmDesc))
+            if needs[i]:
+                cp[i].wino_ws, cp[i].wino_ws_bytes = _ptr(outs[i]), needs[i]
+            cp[i].flags |= L.GG_WS_ONLY
+
+        def make(_p, cp=cp, n=n):
+            L.check(L.load().rehr_gather_gemm_multi_f32(cp, n, _stream()), "rehr_gather_gemm_multi_f32 (weight forms)")
+
+        f = _forms[key] = _Form(key, p, make, dep=pf)
+        f.out = outs
+    _form_ready(f, p)
+    for i in range(n):
+        if needs[i]:
+            descs[i].wino_ws, descs[i].wino_ws_bytes = _ptr(f.out[i]), needs[i]
+        descs[i].flags |= L.GG_WS_READY
+    return f.out
 
 
 def _gg_tag(d):
@@ -270,8 +472,11 @@ def gather_gemm(*args):
         with _timed("gather_gemm_bf16", flops):
             L.check(L.load().rehr_gather_gemm_bf16(C.byref(d), _stream()), "rehr_gather_gemm_bf16")
         return
-    with _timed(_gg_family(d), flops, lambda: _gg_tag(d)):
-        L.check(L.load().rehr_gather_gemm_f32(C.byref(d), _stream()), "rehr_gather_gemm_f32")
+    arr = (L.GatherGemmDesc * 1)(d)
+    keep = _attach_ws(arr, 1, [_gg_desc.need], [_gg_desc.sig], args[11])
+    with _timed(_gg_family(arr[0]), flops, lambda: _gg_tag(arr[0])):
+        L.check(L.load().rehr_gather_gemm_multi_f32(arr, 1, _stream()), "rehr_gather_gemm_f32")
+    del keep
 
 
 def gather_gemm_multi(calls):
@@ -279,17 +484,20 @@ def gather_gemm_multi(calls):
     if len(calls) == 1:
         return gather_gemm(*calls[0])
     arr = (L.GatherGemmDesc * len(calls))()
-    flops, keeps = 0.0, []  # every part keeps its own scratch alive: split-K parts run in ONE launch
+    flops, needs, sigs = 0.0, [], []
     for i, a in enumerate(calls):
         flops += _gg_desc(arr[i], *a)
-        keeps.append(_gg_desc.last_keep)
+        needs.append(_gg_desc.need)
+        sigs.append(_gg_desc.sig)
     if calls[0][0].dtype == torch.bfloat16:
         with _timed("gather_gemm_bf16", flops):
             L.check(L.load().rehr_gather_gemm_multi_bf16(arr, len(calls), _stream()), "rehr_gather_gemm_multi_bf16")
         return
+    keep = _attach_ws(arr, len(calls), needs, sigs, calls[0][11])   # every part its own scratch: ONE launch runs them all
     with _timed(_gg_family(arr[0]) if all(arr[i].wino_ws for i in range(len(calls))) else "gather_gemm", flops,
                 lambda: f"{len(calls)} parts of " + _gg_tag(arr[0])):
         L.check(L.load().rehr_gather_gemm_multi_f32(arr, len(calls), _stream()), "rehr_gather_gemm_multi_f32")
+    del keep
 
 
 def sum_slabs_bias_act(slabs, S, bias, act, slope, stats=None, out_dtype=None):

@@ -16,8 +16,10 @@ LIB_PATH = os.environ.get("REHRSEG_HIP_LIB") or os.path.join(_HERE, "librehrseg_
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rehrseg_hip.h")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 GG_Y_F32 = 1            # rehr_gather_gemm_desc.flags
+GG_WS_READY = 2
+GG_WS_ONLY = 4
 # debug_flags (unstable; tests and A/B tools only -- 0 selects the measured-best kernels)
 DBG_WGRAD_DIRECT = 1    # rehr_wgrad_desc.debug_flags
 DBG_WGRAD_NO_TAP_SKIP = 2

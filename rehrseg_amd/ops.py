@@ -173,16 +173,25 @@ def _out_dims(in_dims, w_shape, cfg: ConvCfg):
     return tuple(conv_out_dim(i, k, s, p) for i, k, s, p in zip(in_dims, K, cfg.stride, cfg.pad))
 
 
-def _pack(w, dest_dim, dtype=torch.float32):
+def _pack(w, dest_dim, dtype=torch.float32, part=None):
     """wp[tap][dest rows (padded)][other dim] in `dtype` (the activations' dtype: fp32, or bf16 on the mixed-precision
-    path -- the master weights `w` stay fp32); dest_dim = which weight dim feeds the output channels."""
+    path -- the master weights `w` stay fp32); dest_dim = which weight dim feeds the output channels.
+    part = (dim, lo, count): of w.narrow(dim, lo, count) (one half of a virtual channel concat; the backend keeps the
+    panels of parameters between steps, so it is told about the parameter, not handed a temporary slice)."""
     be = get_backend()
     T = w.shape[2] * w.shape[3] * w.shape[4]
     kw = {"dtype": torch.bfloat16} if dtype == torch.bfloat16 else {}
+    shape = list(w.shape)
+    if part is not None:
+        if hasattr(be, "invalidate_weight_forms"):
+            kw["part"] = part
+        else:
+            w = w.narrow(*part).contiguous()
+        shape[part[0]] = part[2]
     if dest_dim == 0:
-        A, B = w.shape[0], w.shape[1]
+        A, B = shape[0], shape[1]
         return be.pack_weights(w, A, pad_rows(A), B, T, False, **kw), pad_rows(A)
-    A, B = w.shape[1], w.shape[0]
+    A, B = shape[1], shape[0]
     return be.pack_weights(w, A, pad_rows(A), B, T, True, **kw), pad_rows(A)
 
 
@@ -363,16 +372,14 @@ def conv_dgrad(dz, w, in_dims, c1, c2, cfg: ConvCfg, need1=True, need2=True, x_d
             continue
         if cfg.transposed:
             # dX of ConvTranspose3d = strided Conv3d of dY with w[ci][co] (dest rows = dim 0)
-            wpart = w if (lo == 0 and cnt == w.shape[0]) else w[lo:lo + cnt].contiguous()
-            wp, Npad = _pack(wpart, 0, dz.dtype)
+            wp, Npad = _pack(w, 0, dz.dtype, None if (lo == 0 and cnt == w.shape[0]) else (0, lo, cnt))
             dx = be.new_act(N, cnt, *in_dims, like=dz)
             taps = [full_taps(k) for k in K]
             be.gather_gemm(dz, None, Cz, _spatial(dz), Cz, in_dims, cfg.stride, tuple(-p for p in cfg.pad), taps,
                            K[1], K[2], wp, Npad, dx, in_dims, cnt, (1, 1, 1), (0, 0, 0), None, ACT_NONE, 0.0, None,
                            0, choose_tile(tuple(in_dims)))
         else:
-            wpart = w if (lo == 0 and cnt == w.shape[1]) else w[:, lo:lo + cnt].contiguous()
-            wp, Npad = _pack(wpart, 1, dz.dtype)
+            wp, Npad = _pack(w, 1, dz.dtype, None if (lo == 0 and cnt == w.shape[1]) else (1, lo, cnt))
             if cfg.stride == (1, 1, 1) and cnt % 4 == 0:
                 # low-resolution stages: split the taps like the forward does (one phase, no epilogue)
                 taps = [phase_taps(K[a], 1, cfg.pad[a], 0) for a in range(3)]

@@ -102,6 +102,9 @@ class PatchParallel:
                 dist.broadcast(p.data, src=0, group=process_group)
             for b in module.buffers():
                 dist.broadcast(b.data, src=0, group=process_group)
+            if dev.type == "cuda":      # (written through .data: no version counter moved)
+                from . import hip_backend
+                hip_backend.invalidate_weight_forms()
 
     def _reset_step(self, uses=True):
         """uses=False keeps the forward use counts: the reference's loops clear gradients AFTER the forward
@@ -120,8 +123,9 @@ class PatchParallel:
         self._ops.unregister_direct_grad(self)
 
     # ------------------------------------------------------------------ bucket exchange
-    def _collect(self, i):
-        """Reconcile bucket i's slots with what `.grad` holds; afterwards every `.grad` is its view again."""
+    def _collect(self, i, on_side=None):
+        """Reconcile bucket i's slots with what `.grad` holds; afterwards every `.grad` is its view again.
+        on_side: the stream this runs on when it is not the stream the gradients were produced on."""
         src, dst, zero = [], [], []
         for p in self._params_of_bucket[i]:
             v = self._view[id(p)]
@@ -136,6 +140,11 @@ class PatchParallel:
             torch._foreach_zero_(zero)
         if src:
             torch._foreach_copy_(dst, src)
+            if on_side is not None:
+                # autograd allocated these on the backward's stream and `p.grad = v` above dropped the last reference:
+                # the allocator must not hand the blocks out again before the side stream's copy has read them
+                for t in src:
+                    t.record_stream(on_side)
 
     def wgrad_stream(self):
         """The side stream the direct-route weight-gradient kernels run on (None: everything on the current stream)."""
@@ -187,7 +196,7 @@ class PatchParallel:
             if other is not None:
                 self._side.wait_stream(other)
             with torch.cuda.stream(self._side):
-                self._collect(i)
+                self._collect(i, on_side=self._side)
                 self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._collect(i)
@@ -237,6 +246,10 @@ class PatchParallel:
         overlap disabled) are exchanged here.  Ends the step's bookkeeping, so the next backward
         starts clean whether or not `zero_grad()` of this object is called in between."""
         self._join_side()
+        if self.flat.is_cuda:
+            # the optimizer step that follows overwrites the parameters: behind the last rebuild of their kernel forms
+            from . import hip_backend
+            hip_backend.join_weight_forms()
         if not self.exchange:
             # single rank: handed-over gradients stay where autograd put them (the optimizer reads p.grad)
             self._written.clear()
