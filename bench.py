@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--no-teacher-stream", action="store_true",
                     help="cfg4 / cfg5: the frozen teacher's pass on the main stream (default: a second HIP stream, next to "
                          "the student's forward)")
+    ap.add_argument("--no-form-cache", action="store_true",
+                    help="frozen networks (cfg4 / cfg5: the teacher) re-pack their weights at every launch too")
     ap.add_argument("--kernel-steps", type=int, default=0,
                     help="steps of the separate per-kernel timing pass (0: max(--steps, 50), at most 100)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -172,6 +174,7 @@ def main():
 
     from rehrseg_amd import hip_backend
     from rehrseg_amd.parallel import PatchParallel
+    hip_backend.WEIGHT_FORM_CACHE = not args.no_form_cache
 
     if args.workload == "cfg5":   # BASELINE.json configs[4]: the joint step in bf16 mixed precision at 160^3
         args.workload = "cfg4"

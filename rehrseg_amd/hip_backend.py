@@ -163,17 +163,22 @@ def new_act(N, Cc, D, H, W, like, zero=False, dtype=None):
 
 # ---- weight forms kept across launches ----------------------------------------------------------------------------
 # A convolution needs its weights as a kernel panel (pack_weights) and, on the fp32 Winograd kernels, as
-# transform-domain fragments (the library's weight-transform launch into `wino_ws`): two 5-20 us launches of a few
-# blocks each in front of every forward and every input-gradient kernel, 95 per cfg-2 step = 1.5 ms of a mostly idle
-# chip.  Both depend on the parameter's VALUES and the layer geometry only, so they are kept per (parameter, geometry)
-# and rebuilt when the parameter has changed: its version counter has moved (load_state_dict, any in-place torch op) or
-# an optimizer has stepped over it (torch's fused optimizers do NOT move version counters, so a global
-# optimizer-step post hook stamps the parameters of every optimizer that steps).  A write through `.data` is seen by
-# neither, by torch's design: call invalidate_weight_forms() after one.  The first request that meets a stale form rebuilds ALL stale forms, in the order they were first asked
-# for, on a second stream next to the forward's first kernels; a consumer waits for its form's event.  Frozen
-# networks (the joint step's teacher, inference) keep their forms for good.
-WEIGHT_FORM_CACHE = True     # False: every call packs / transforms on its own stream (tests compare the two)
-WEIGHT_FORM_STREAM = True    # False: stale forms are rebuilt one by one where they are needed, on the caller's stream
+# transform-domain fragments (the library's weight-transform launch into `wino_ws`): two 5-20 us launches in front of
+# every forward and every input-gradient kernel.  Both depend on the parameter's VALUES and the layer geometry only.
+# For weights that take no gradient in the pass at hand -- frozen parameters, passes under torch.no_grad(): the joint
+# step's teacher, the tiled predictor walking hundreds of tiles, validation -- they are kept per (parameter, geometry)
+# and rebuilt, where they are needed, when the
+# parameter has changed: its version counter has moved (load_state_dict, any in-place torch op) or an optimizer has
+# stepped over it (torch's fused optimizers do NOT move version counters, so a global optimizer-step post hook stamps
+# the parameters of every optimizer that steps).  A write through `.data` is seen by neither, by torch's design: call
+# invalidate_weight_forms() after one.
+# Trainable parameters in a recorded pass are NOT kept: every form would be stale once per step anyway.  Rebuilding all
+# stale forms of a step in one batch in front of the first convolution (on one side stream next to the forward, or
+# fanned out over 2 / 4 / 8 streams and joined) was measured and is SLOWER than the launches where they stand
+# (profiles/r03_ab_weight_forms.txt: cfg-2 +0.4..0.6 ms, cfg-3 +0.6..1.0 ms): in line, each small launch runs in the
+# shadow of the matrix-core kernels around it, whose clocks the power budget sets -- the 1.5 ms these launches sum to in
+# a kernel trace is not on the step's critical path.
+WEIGHT_FORM_CACHE = True     # False: every call packs / transforms for itself (tests compare the two)
 
 
 def _after_optimizer_step(opt, args, kwargs):
@@ -190,26 +195,30 @@ def _ver(p):
     return (p._version, getattr(p, "_rehr_stamp", 0))
 
 
+keep_forms = False           # set by ops.fused_conv3d / _FusedConv.backward in front of every launch sequence: the weight of this node takes
+                             # no gradient in this pass (frozen parameter, or nothing is being recorded)
+
+
+def _keeps_forms(w):
+    return WEIGHT_FORM_CACHE and keep_forms and isinstance(w, torch.nn.Parameter)
+
+
 class _Form:
-    __slots__ = ("param", "version", "out", "make", "event", "made_on", "seen_by", "dep", "ticket", "__weakref__")
+    __slots__ = ("param", "version", "out", "make", "stream", "readers", "dep", "__weakref__")
 
     def __init__(self, key, param, make, dep=None):
         self.param = weakref.ref(param, lambda _r, k=key: _drop_form(k))   # the forms go when the parameter goes
-        self.version = None          # parameter version `out` was made from
+        self.version = None          # _ver(parameter) `out` was made from
         self.out = None              # pack: the panel tensor; Winograd: list of scratch tensors (one per descriptor)
         self.make = make             # make(parameter): launches the rebuild on the current stream
-        self.event = None
-        self.made_on = None          # stream handle the last rebuild ran on
-        self.seen_by = set()         # stream handles that are ordered behind that rebuild
+        self.stream = None           # the stream of the last rebuild
+        self.readers = set()         # streams that have consumed `out` since (a rebuild has to wait for them)
         self.dep = dep               # Winograd forms: the pack form they read
-        self.ticket = 0              # number of the batch rebuild that made it (0: made in place)
 
 
-_forms = {}                # key -> _Form, in first-request order
+_forms = {}                # key -> _Form
 _form_of_panel = {}        # id(panel tensor) -> pack form (Winograd forms find the parameter behind a `wp`)
-_form_streams = {}         # device index -> side stream
-_form_batch = {"ticket": 0, "done": None, "count": 0, "used": 0, "joined": True}
-form_rebuilds = 0          # launches issued for rebuilding forms (tests look at this)
+form_rebuilds = 0          # launches issued for (re)building kept forms (tests look at this)
 
 
 def _drop_form(key):
@@ -220,87 +229,29 @@ def _drop_form(key):
 
 def invalidate_weight_forms():
     """Forget every kept weight form (after writing parameters through `.data`, which no version counter sees)."""
-    join_weight_forms()
     _forms.clear()
     _form_of_panel.clear()
 
 
-def join_weight_forms():
-    """The current stream waits for the last batch rebuild (before parameters are overwritten by something torch's
-    stream order does not already put behind every consumer of the forms; PatchParallel.reduce_gradients calls it)."""
-    b = _form_batch
-    if not b["joined"] and b["done"] is not None:
-        torch.cuda.current_stream().wait_event(b["done"])
-        b["joined"] = True
-
-
 def _form_ready(f, p):
-    """Make form `f` of parameter `p` current and order the current stream behind its rebuild."""
-    cur = torch.cuda.current_stream(p.device)
-    if f.version != _ver(p) or (f.dep is not None and f.dep.version != _ver(p)):
-        if WEIGHT_FORM_STREAM and f.version is not None and not _form_batch.get("running"):
-            _rebuild_stale(p.device, cur)
-        if f.version != _ver(p):                    # first sight (or the batch did not reach it): in place
-            if f.dep is not None:
-                _form_ready(f.dep, p)
-            if f.event is not None and f.made_on != cur.cuda_stream:
-                cur.wait_event(f.event)                 # an older rebuild on another stream may still be writing
-            _make(f, p, cur, 0)
-    h = cur.cuda_stream
-    if f.made_on != h and h not in f.seen_by:
-        cur.wait_event(f.event)
-        f.seen_by.add(h)
-    b = _form_batch
-    if f.ticket and f.ticket == b["ticket"] and not b["joined"]:
-        # the whole batch is joined once a quarter of it has been consumed: long before that the side stream has
-        # drained, and from then on the next optimizer step is ordered behind every read of the parameters
-        b["used"] += 1
-        if b["used"] * 4 >= b["count"]:
-            cur.wait_event(b["done"])
-            b["joined"] = True
-
-
-def _make(f, p, stream, ticket):
+    """Make form `f` of parameter `p` current and order the current stream behind its last rebuild."""
     global form_rebuilds
-    f.make(p)
-    form_rebuilds += 1
-    f.version = _ver(p)
-    if f.event is None:
-        f.event = torch.cuda.Event()
-    f.event.record(stream)
-    f.made_on = stream.cuda_stream
-    f.seen_by = set()
-    f.ticket = ticket
-
-
-def _rebuild_stale(device, cur):
-    """All stale forms of parameters on `device`, in first-request order, on the side stream."""
-    side = _form_streams.get(device.index)
-    if side is None:
-        side = _form_streams[device.index] = torch.cuda.Stream(device=device)
-    b = _form_batch
-    join_weight_forms()                                 # (an unjoined older batch: finish it first)
-    side.wait_stream(cur)                               # behind the update of the parameters, behind every old reader
-    b["running"] = True
-    n = 0
-    try:
-        with torch.cuda.stream(side):
-            tk = b["ticket"] + 1
-            for k in list(_forms):
-                f = _forms.get(k)
-                p = f.param() if f is not None else None
-                if p is None or p.device != device or f.version is None:
-                    continue
-                if f.version != _ver(p) and (f.dep is None or f.dep.version == _ver(p)):
-                    _make(f, p, side, tk)
-                    n += 1
-            if n:
-                if b["done"] is None:
-                    b["done"] = torch.cuda.Event()
-                b["done"].record(side)
-                b.update(ticket=tk, count=n, used=0, joined=False)
-    finally:
-        b["running"] = False
+    cur = torch.cuda.current_stream(p.device)
+    v = _ver(p)
+    if f.version != v:
+        if f.dep is not None:
+            _form_ready(f.dep, p)
+        for r in f.readers:                             # nobody may still be reading what is overwritten
+            if r != cur:
+                cur.wait_stream(r)
+        if f.stream is not None and f.stream != cur:
+            cur.wait_stream(f.stream)
+        f.make(p)
+        form_rebuilds += 1
+        f.version, f.stream, f.readers = v, cur, set()
+    if f.stream != cur and cur not in f.readers:        # made on another stream: once per rebuild and consumer stream
+        cur.wait_stream(f.stream)
+    f.readers.add(cur)
 
 
 def _pack_launch(src, out, A, Apad, B, T, transpose):
@@ -315,7 +266,7 @@ def _pack_launch(src, out, A, Apad, B, T, transpose):
 def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32, part=None):
     """fp32 master weights in the torch parameter layout -> kernel panel [T][Apad][B] in `dtype` (fp32 / bf16).
     `part` = (dim, lo, count): the panel of w.narrow(dim, lo, count) (the halves of a virtual channel concat).
-    Panels of nn.Parameters are kept until the parameter changes (see "weight forms" above)."""
+    Panels of frozen parameters / of no-grad passes are kept until the parameter changes ("weight forms" above)."""
     _chk_dev(w)
     if w.dtype != torch.float32:
         raise L.RehrsegHipError("master weights are float32")
@@ -323,7 +274,7 @@ def pack_weights(w, A, Apad, B, T, transpose, dtype=torch.float32, part=None):
     def src(p):
         return (p if part is None else p.narrow(*part)).contiguous()
 
-    if not (WEIGHT_FORM_CACHE and isinstance(w, torch.nn.Parameter)):
+    if not _keeps_forms(w):
         out = torch.empty((T, Apad, B), dtype=dtype, device=w.device)
         _pack_launch(src(w), out, A, Apad, B, T, transpose)
         return out
@@ -423,7 +374,7 @@ def _attach_ws(descs, n, needs, sigs, wp):
     dev = wp.device
     pf = _form_of_panel.get(id(wp)) if WEIGHT_FORM_CACHE else None
     p = pf.param() if pf is not None else None
-    if p is None:
+    if p is None or not _keeps_forms(p):
         keeps = [torch.empty(nb // 4, dtype=torch.float32, device=dev) if nb else None for nb in needs]
         for i in range(n):
             if needs[i]:

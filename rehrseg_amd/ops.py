@@ -553,6 +553,7 @@ class _FusedConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         be = get_backend()
+        be.keep_forms = not ctx.needs_input_grad[2]
         cfg = ctx.cfg
         x1, x2, w, p1, p2, y0, y, gate, mean, mr = ctx.saved_tensors
         has_x2, has_b, has_res = ctx.has
@@ -662,6 +663,9 @@ def fused_conv3d(x, w, b=None, stride=1, padding=0, *, x2=None, transposed=False
         x = x if x.dtype == want else x.to(want)
         x2 = x2 if (x2 is None or x2.dtype == want) else x2.to(want)
         res = res if (res is None or res.dtype == want) else res.to(want)
+    # weights that take no gradient in this pass (frozen, or nothing is recorded): the backend may keep their kernel
+    # forms between launches (hip_backend, "weight forms"; the backward pass of a recorded node says the same for itself)
+    get_backend().keep_forms = not (w.requires_grad and torch.is_grad_enabled())
     return _FusedConv.apply(x, x2, w, b, p1, p2, res, cfg)
 
 

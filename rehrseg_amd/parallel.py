@@ -246,10 +246,6 @@ class PatchParallel:
         overlap disabled) are exchanged here.  Ends the step's bookkeeping, so the next backward
         starts clean whether or not `zero_grad()` of this object is called in between."""
         self._join_side()
-        if self.flat.is_cuda:
-            # the optimizer step that follows overwrites the parameters: behind the last rebuild of their kernel forms
-            from . import hip_backend
-            hip_backend.join_weight_forms()
         if not self.exchange:
             # single rank: handed-over gradients stay where autograd put them (the optimizer reads p.grad)
             self._written.clear()
