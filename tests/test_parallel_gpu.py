@@ -119,39 +119,74 @@ def test_hook_launched_buckets_with_direct_writes_under_rccl_world1(tmp_path):
 
 def test_side_stream_weight_gradients_change_nothing():
     """PatchParallel(wgrad_stream=True): the direct-route weight-gradient kernels run on a second HIP stream while the
-    main stream continues with the input-gradient chain.  Same kernels on the same operands: after the join in
-    reduce_gradients() every gradient -- and, after three optimizer steps, every parameter -- equals the single-stream
-    run to the run-to-run reproducibility of the path (the fp64 statistics atomics of the SEGating epilogues commute
-    only up to rounding: two single-stream runs differ by the same few ulp, measured alongside); a second accumulated
-    backward pass (autograd accumulates into directly written slots) too.  A race would show as O(1) errors."""
+    main stream continues with the input-gradient chain.  Same kernels on the same operands, so the gradients must
+    equal the single-stream ones.
+
+    Gradients are compared on ONE recorded graph, backpropagated once per stream setting: two separate forward passes
+    are not bit-identical (the SEGating means are fp64 atomics rounded to fp32: last-bit differences), and a
+    pre-activation that sits within rounding of zero then flips its ReLU mask -- one voxel of one channel, which moves
+    that channel's weight gradient by ~1e-3 of the tensor's largest element (tools/check_determinism.py shows the two
+    modes; measured in round 3 when this test compared separate runs and failed one time in six).  On a shared graph
+    the masks are shared and what is left is the summation order of the backward's own fp64 atomics: a few 1e-7.
+    Also: a second accumulated backward pass (autograd accumulates into directly written slots), and three optimizer
+    steps with each setting (parameters: loose bar, separate forwards).  A race would show as O(1) errors."""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
     x = torch.rand(2, 2, 4, 48, 40, generator=g).to(dev)
+
+    def rel(a, b):
+        per = {n: float((a[n] - b[n]).abs().max()) / (float(a[n].abs().max()) + 1e-30) for n in a}
+        worst = max(per, key=per.get)
+        return per[worst], (worst, float(a[worst].abs().max()))
+
+    def grads(m):
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    # ---- one graph, three backward passes: single stream, side stream, single stream again (the yardstick)
+    m = _model(dev)
+    pp = PatchParallel(m, wgrad_stream=True)
+    assert pp.wgrad_stream() is not None
+    loss = m(x.clone()).abs().mean()
+    uses = dict(pp._uses)                                     # the forward's use counts (reduce_gradients ends a step
+    got = {}                                                  # and clears them: re-armed for every pass over the graph)
+    for tag, side in (("single", False), ("side", True), ("again", False)):
+        pp.set_wgrad_stream(side)
+        assert (pp.wgrad_stream() is not None) == side
+        pp._uses = dict(uses)
+        pp.zero_grad()
+        loss.backward(retain_graph=True)
+        assert len(pp._written) >= 20                         # the direct route (the one that uses the side stream)
+        pp.join_side()
+        torch.cuda.synchronize()
+        got[tag] = grads(m)
+        loss.backward(retain_graph=True)                      # accumulated on top (autograd's accumulation route)
+        pp.reduce_gradients()
+        torch.cuda.synchronize()
+        got[tag + "+acc"] = grads(m)
+    for k in ("", "+acc"):
+        repro, _ = rel(got["single" + k], got["again" + k])
+        d, where = rel(got["single" + k], got["side" + k])
+        print("side stream vs single stream, gradients" + k, d, "run-to-run", repro, where)
+        assert d <= max(2e-6, 4 * repro), (k, d, repro, where)
+    for n, t in got["single+acc"].items():                    # (and the accumulation really doubled them)
+        assert float((t - 2 * got["single"][n]).abs().max()) <= 1e-5 * (float(t.abs().max()) + 1e-30), n
+    pp.close()
+    del loss, got
+
+    # ---- three optimizer steps with each setting: the parameters agree (separate forwards: mask flips allowed for)
     res = {}
-    for side in (False, True, "again"):
-        tag, side = side, bool(side) if side != "again" else False
+    for side in (False, True):
         m = _model(dev)
         pp = PatchParallel(m, wgrad_stream=side)
-        assert (pp.wgrad_stream() is not None) == side
         opt = torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.9)
         for _ in range(3):
             pp.zero_grad()
             m(x.clone()).abs().mean().backward()
             pp.reduce_gradients()
             opt.step()
-        pp.zero_grad()
-        for _ in range(2):                                   # accumulation over two passes
-            m(x.clone()).abs().mean().backward()
-        pp.reduce_gradients()
         torch.cuda.synchronize()
-        res[tag] = ({n: p.detach().clone() for n, p in m.named_parameters()},
-                    {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        res[side] = {n: p.detach().clone() for n, p in m.named_parameters()}
         pp.close()
-
-    def dist_(a, b):
-        return max(float((a[n] - b[n]).abs().max()) / (float(a[n].abs().max()) + 1e-30) for n in a)
-    for k in (0, 1):
-        repro = dist_(res[False][k], res["again"][k])           # two single-stream runs
-        d = dist_(res[False][k], res[True][k])
-        print("side stream vs single stream:", "parameters" if k == 0 else "gradients", d, "run-to-run", repro)
-        assert d <= max(1e-5, 4 * repro), (k, d, repro)
+    d, where = rel(res[False], res[True])
+    print("side stream vs single stream, parameters after 3 steps", d, where)
+    assert d <= 1e-4, (d, where)
