@@ -155,3 +155,39 @@ def test_teacher_stem_shared_between_windows_gpu():
         assert a.shape == e.shape
         err = ((a - e).abs().max() / e.abs().max()).item()
         assert err <= 2e-5, err
+
+
+def test_teacher_on_its_own_stream_changes_nothing():
+    """train_segsr_step(teacher_stream=True) runs the frozen teacher's pass on a second HIP stream next to the student's
+    forward.  Same kernels on the same operands: the loss and every gradient of the step equal the
+    single-stream step's up to the summation order of the fp64 statistics atomics.  A missing join or a recycled buffer
+    would show as O(1) errors (the shared zero-accumulator pool did, as NaN, before it was keyed per stream)."""
+    import itertools
+    dev = torch.device("cuda:0")
+    teacher, _ = _flavr(True, dev)
+    teacher.eval()
+    img = det_input("st2.img", (2, 1, 6, 32, 32), "rand") * 2 + 0.5
+    lab_lr = det_input("st2.lr", (2, 1, 6, 32, 32), "randint2").to(dev)
+    lab_hr = det_input("st2.hr", (2, 1, 24, 32, 32), "randint2").to(dev)
+    unc = (1 - det_input("st2.u", (2, 1, 6, 32, 32), "rand") * 0.99).to(dev)
+    out = {}
+    for tag, side in (("single", False), ("side", True), ("again", False)):
+        student, _ = build(PLAN, dev)
+        dist = Distiller(64, 64, 0.0, 1.0, 1.0)
+        dist.load_state_dict({k: det_tensor(k, tuple(v.shape)) for k, v in dist.state_dict().items()})
+        dist = dist.to(dev)
+        params = list(itertools.chain(student.parameters(), dist.parameters()))
+        opt = torch.optim.SGD(params, lr=0.0)                 # lr 0: the step leaves the gradients to look at
+        loss = train_segsr_step(student, teacher, dist, opt, img.clone().to(dev), lab_lr, lab_hr, unc,
+                                su._build_loss(False, weight_dice=0), su._build_loss(False, weight_dice=1),
+                                teacher_stream=side)
+        torch.cuda.synchronize()
+        out[tag] = (float(loss), [p.grad.detach().clone() if p.grad is not None else None for p in params])
+
+    def worst(a, b):
+        return max(float((x - y).abs().max()) / (float(x.abs().max()) + 1e-30) for x, y in zip(a, b) if x is not None)
+    repro = worst(out["single"][1], out["again"][1])
+    d = worst(out["single"][1], out["side"][1])
+    print("teacher stream vs single stream: loss", out["side"][0], out["single"][0], "gradients", d, "run-to-run", repro)
+    assert abs(out["side"][0] - out["single"][0]) <= 1e-6 * abs(out["single"][0])
+    assert d <= max(2e-6, 4 * repro), (d, repro)
