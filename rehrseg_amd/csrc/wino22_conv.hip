@@ -195,10 +195,11 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
 
-  auto kstep = [&](int buf, const int kk, const f32x4 (&ub)[3]) {
+  // A fragments of k-group kk of slice buffer `buf`: v = B^T d B restricted to this wave's Winograd row
+  auto read_a = [&](int buf, const int kk, f32x4 (&v)[3]) {
     f32x4 R[3];
 #ifdef W22_DBG_NOLDS   // (timing diagnostics only: wrong results)
-    R[0] = R[1] = R[2] = ub[0];
+    R[0] = R[1] = R[2] = f32x4{1.f, 2.f, 3.f, 4.f};
 #else
 #pragma unroll
     for (int j = 0; j < 3; ++j) R[j] = *reinterpret_cast<const f32x4*>(xa + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
@@ -207,43 +208,87 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
       for (int j = 0; j < 3; ++j) R[j] -= *reinterpret_cast<const f32x4*>(xb + buf + ((j & 1) * 9 + (j >> 1)) * LD + kk * 8);
     }
 #endif
-    f32x4 v[3];
     v[0] = R[0] - R[1];
     v[1] = R[1];
     v[2] = R[2] - R[1];
+  };
+  auto mma = [&](const f32x4 (&v)[3], const f32x4 (&ub)[3]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
   };
 
-  // item loop: weights one k-group ahead in registers, next item's patch fetched at the top and written to
-  // the other LDS slice at the bottom; the three waves of a SIMD hide each other's LDS latency
-  f32x4 u0[3], u1[3];
-  Item cur_i = {0, 0, min(jd_lo, d.td.count - 1)}, nxt_i = cur_i;
+  // Item loop.  Weights AND A fragments run one k-group ahead in registers, and the item barrier sits between the third
+  // and the fourth k-group: behind it every wave still holds a k-group's operands (12 MFMAs) and has already asked for
+  // the next item's first fragments.  (Round 3, s_memtime stamps: with the barrier at the end of an item all 12 waves
+  // came out of it with nothing but address arithmetic and LDS latency in front of them -- 12.4k cycles per item for
+  // 9.2k cycles of matrix-pipe work.)  s_setprio: the issue arbiter serves the oldest wave of a SIMD first, so the first
+  // of its three waves ran its four k-groups back to back and then sat at the barrier for two thirds of an item while
+  // the last one worked alone (stamps: 45-64k of 143k cycles waiting); a wave's priority now falls with every k-group
+  // since the barrier, which makes the arbiter prefer whoever is behind.
+#ifdef W22_STAMPS   // (timing diagnostics only)
+  const long long st0 = __builtin_readcyclecounter();
+#endif
+  f32x4 u0[3], u1[3], va[3], vb[3];
+  Item cur_i = {0, 0, min(jd_lo, d.td.count - 1)}, nxt_i = cur_i, fet_i;
   fetch(cur_i);
   load_u(cur_i, 0, u0);
   stage(0);
+  advance(nxt_i);
+  fetch(nxt_i);                      // patch 1 travels while item 0 computes (an item past the end loads zeros)
+  fet_i = nxt_i;
   __syncthreads();
+  read_a(0, 0, va);
+#ifdef W22_STAMPS
+  const long long st1 = __builtin_readcyclecounter();
+  long long st_stage = 0, st_bar = 0;
+#endif
   for (int it = 0; it < items; ++it) {
     const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
-    advance(nxt_i);
-    fetch(nxt_i);
     load_u(cur_i, 1, u1);
-    kstep(cur, 0, u0);
+    read_a(cur, 1, vb);
+    __builtin_amdgcn_s_setprio(2);
+    mma(va, u0);
     load_u(cur_i, 2, u0);
-    kstep(cur, 1, u1);
+    read_a(cur, 2, va);
+    __builtin_amdgcn_s_setprio(1);
+    mma(vb, u1);
     load_u(cur_i, 3, u1);
-    kstep(cur, 2, u0);
-    load_u(nxt_i, 0, u0);
-    kstep(cur, 3, u1);
-    stage(nxt);
-    cur_i = nxt_i;
+    read_a(cur, 3, vb);
+    __builtin_amdgcn_s_setprio(0);
+    mma(va, u0);
+#ifdef W22_STAMPS
+    const long long sa = __builtin_readcyclecounter();
+#endif
+    __builtin_amdgcn_s_setprio(3);   // everybody waits for the slowest stage: it goes first
+    stage(nxt);                      // patch it + 1, asked for a whole item ago
+#ifdef W22_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long sb = __builtin_readcyclecounter();
+#endif
 #ifndef W22_DBG_NOBAR
     __syncthreads();
 #endif
+#ifdef W22_STAMPS
+    const long long sc = __builtin_readcyclecounter();
+    st_stage += sb - sa;
+    st_bar += sc - sb;
+#endif
+    load_u(nxt_i, 0, u0);
+    read_a(nxt, 0, va);
+    __builtin_amdgcn_s_setprio(3);
+    mma(vb, u1);
+    advance(fet_i);
+    fetch(fet_i);                    // patch it + 2 (address arithmetic under the MFMAs just issued)
+    cur_i = nxt_i;
+    nxt_i = fet_i;
   }
+  __builtin_amdgcn_s_setprio(0);
 
+#ifdef W22_STAMPS
+  const long long st2 = __builtin_readcyclecounter();
+#endif
   // ---- output transform Y = A^T M A, A^T = [[1,1,0],[0,1,1]]: columns in registers, rows through LDS
   float* ex = smem;  // [fm*2+fn][r 3][c' 2][q][lane]
   {
@@ -310,6 +355,13 @@ __global__ __launch_bounds__(NT_) void wino22_conv_kernel(const W22Params p) {
       }
     }
   }
+#ifdef W22_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  const long long st3 = __builtin_readcyclecounter();
+  if (lane == 0 && (blockIdx.x % 509) == 0 && blockIdx.z == 0)
+    printf("w22 block %d wave %d items %d: prologue %lld  kloop %lld (stage waits %lld, barrier waits %lld)  epilogue %lld\n",
+           (int)blockIdx.x, wv, items, st1 - st0, st2 - st1, st_stage, st_bar, st3 - st2);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,6 +544,9 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
       for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
   };
 
+#ifdef W22_STAMPS   // (timing diagnostics only)
+  const long long st0 = __builtin_readcyclecounter();
+#endif
   f32x4 u0[3], u1[3];
   Item cur_i = {0, 0, min(jd_lo, d.td.count - 1)}, nxt_i = cur_i;
   fetch(cur_i);
@@ -515,6 +570,9 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
     __syncthreads();
   }
 
+#ifdef W22_STAMPS
+  const long long st2 = __builtin_readcyclecounter();
+#endif
   // ---- output transform Y = A^T M A, A^T = [[1,1,0],[0,1,1]]: columns in registers, rows through LDS
   float* ex = smem;  // [fm*2+fn][r 3][c' 2][q][lane]
   {
