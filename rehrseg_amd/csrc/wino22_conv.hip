@@ -544,9 +544,6 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
       for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][e], ub[c][e], acc[c], 0, 0, 0);
   };
 
-#ifdef W22_STAMPS   // (timing diagnostics only)
-  const long long st0 = __builtin_readcyclecounter();
-#endif
   f32x4 u0[3], u1[3];
   Item cur_i = {0, 0, min(jd_lo, d.td.count - 1)}, nxt_i = cur_i;
   fetch(cur_i);
@@ -570,9 +567,6 @@ __global__ __launch_bounds__(NT_) void wino22_flat_conv_kernel(const F22Params p
     __syncthreads();
   }
 
-#ifdef W22_STAMPS
-  const long long st2 = __builtin_readcyclecounter();
-#endif
   // ---- output transform Y = A^T M A, A^T = [[1,1,0],[0,1,1]]: columns in registers, rows through LDS
   float* ex = smem;  // [fm*2+fn][r 3][c' 2][q][lane]
   {

@@ -537,6 +537,11 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
 #ifndef BIG8_FENCE
 #define BIG8_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifdef BIG8_NO_PRIO   // (A/B builds)
+#define BIG8_PRIO(n) (void)0
+#else
+#define BIG8_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
 #define BIG8_KGROUP(kk, vcur, vnext, NEXT_T, NEXT_KK, READS, EXTRA0, EXTRA1)  \
   BIG8_FENCE();                                                               \
   READS;                                                                      \
@@ -553,18 +558,24 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
   for (int it = 0; it < items; ++it) {
     const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
     advance(ni);
+    // (s_setprio: a wave's issue priority falls with its progress since the item barrier, so that the arbiter -- oldest
+    // wave first by default -- serves the wave of a SIMD that is behind; see wino22_conv.hip)
+    BIG8_PRIO(2);
     BIG8_KGROUP(0, VA, VB, ci, 1, issue_reads(cur, 1), fetch(ni, 0), (void)0)
+    BIG8_PRIO(1);
     BIG8_KGROUP(1, VB, VA, ci, 2, issue_reads(cur, 2), (void)0, stage(nxt, 0))
     BIG8_KGROUP(2, VA, VB, ci, 3, issue_reads(cur, 3), fetch(ni, NXH), (void)0)
     // last k-group of the item: its A fragments are in VB and nobody reads the current patch any more, so the barrier
     // sits between its two half steps and the next item's first fragments are read and combined behind 16 MFMAs
     __builtin_amdgcn_sched_barrier(0);
+    BIG8_PRIO(0);
     stage(nxt, NXH);
     mfmas(0, VB, u0);
     __builtin_amdgcn_sched_barrier(0);
     load_u(ni, 0, 0, u0);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+    BIG8_PRIO(3);
     issue_reads(nxt, 0);
     mfmas(1, VB, u1);
     combine(VA);
@@ -573,6 +584,7 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
     ci = ni;
   }
 #undef BIG8_KGROUP
+  BIG8_PRIO(0);
   __syncthreads();
 
   // ---- output transform: columns in registers, rows across the 4 row-waves of a tile group through LDS

@@ -407,15 +407,23 @@ __global__ __launch_bounds__(256 * WS, MINB_) void wino_wgrad_kernel(const WWPar
       prep_xform(j, w, ZP, VP);
     }
 
+#ifdef WW_NO_PRIO   // (A/B builds)
+#define WW_PRIO(n) (void)0
+#else
+#define WW_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
     for (int st = 0; st < nstages; ++st) {
       const int cur = (st & 1) * BUF, nxt = cur ^ BUF;
       // tile row 0 with set P; set Q <- tile row 1 of this stage.  Staging: second half of stage
       // st+1 lands in nxt (free since the previous midpoint), first half of st+2 is fetched.
+      WW_PRIO(1);   // (issue priority falls with progress since the barrier: the arbiter serves the wave that is behind)
       kgroup(ZP, VP, cur, 1, ZQ, VQ, nxt, integral_constant<bool, false>{});
       // midpoint: nobody reads `cur` any more, stage st+1 is complete in `nxt`
       __syncthreads();
+      WW_PRIO(2);
       kgroup(ZQ, VQ, nxt, 0, ZP, VP, cur, integral_constant<bool, true>{});
     }
+    WW_PRIO(0);
   }
 
   if (p.slab_bias != nullptr && r == 1 && jd == p.bias_jd && ct == 0) {
