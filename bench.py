@@ -157,19 +157,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if launched and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
-    on_cpu = args.backend == "gloo"
-    if on_cpu and args.workload != "stub":
-        raise SystemExit("--backend gloo runs the stub workload only: the product path has no CPU fallback")
+    on_cpu = args.workload == "stub" and args.backend == "gloo"
+    if args.workload == "stub" and not on_cpu:
+        raise SystemExit("--workload stub is the CPU plumbing test: use it with --backend gloo")
+    # --backend gloo with a real workload = REHEARSAL of the N > 1 path on a box with fewer GPUs than ranks: the ranks share
+    # the devices round-robin and gloo carries the gradient buckets through the host.  The line it prints is not a
+    # measurement (config.rehearsal says so); the product path itself still has no CPU fallback.
+    rehearsal = args.backend == "gloo" and not on_cpu
+    n_dev = 1 if on_cpu else max(1, torch.cuda.device_count())   # (counting devices initialises nothing)
+    dev_index = local_rank % n_dev if rehearsal else local_rank
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if not on_cpu:
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(dev_index)
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     if on_cpu:
         dev = torch.device("cpu")
     else:
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", dev_index)
         torch.cuda.set_device(dev)
 
     from rehrseg_amd import hip_backend
@@ -403,7 +409,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "patches_per_gpu": patches_per_step,
                        "global_batch": world * patches_per_step,
-                       "parallelism": f"dp{world} (patch-parallel, flat-bucket RCCL all-reduce)"},
+                       "parallelism": f"dp{world} (patch-parallel, flat-bucket RCCL all-reduce)"
+                                      + (" -- REHEARSAL: gloo ranks sharing devices, not a measurement" if rehearsal else "")},
             "loss": final_loss,
         }
         if step_ms:

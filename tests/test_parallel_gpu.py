@@ -117,6 +117,75 @@ def test_hook_launched_buckets_with_direct_writes_under_rccl_world1(tmp_path):
     assert res["written"][0] >= 20 and res["written"][1] == 0 and res["written"][2] >= 20, res
 
 
+TWO_RANK_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)                                        # both ranks share the one device of the box
+dist.init_process_group("gloo", rank=rank, world_size=2)        # gloo moves device tensors through the host
+from oracle.detinit import det_tensor
+from rehrseg_amd.models.FLAVR.FLAVR_arch import UNet_3D_3D
+from rehrseg_amd.parallel import PatchParallel
+dev = torch.device("cuda:0")
+def model():
+    m = UNet_3D_3D(2, "unet_18", 4, 4)
+    m.load_state_dict({{k: det_tensor(k, tuple(v.shape)) for k, v in m.state_dict().items()}})
+    return m.to(dev)
+xs = [torch.rand(2, 2, 4, 32, 32, generator=torch.Generator().manual_seed(20 + r)).to(dev) for r in range(2)]
+# what the exchange must produce: the mean over the two ranks' patches of the single-rank gradients
+want = None
+for r in range(2):
+    ref = model()
+    ref(xs[r].clone()).abs().mean().backward()
+    g = {{n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}}
+    want = g if want is None else {{n: (want[n] + g[n]) / 2 for n in g}}
+    del ref
+m = model()
+pp = PatchParallel(m, bucket_mb=8)                              # world 2: hooks launch the buckets during backward
+assert pp.world == 2 and pp.overlap and pp.exchange and len(pp.buckets) >= 8 and pp.wgrad_stream() is not None
+worst, launched, written = 0.0, [], []
+for step in range(3):
+    pp.zero_grad()
+    m(xs[rank].clone()).abs().mean().backward()
+    launched.append(sum(pp._launched))
+    written.append(len(pp._written))
+    pp.reduce_gradients()
+    for n, p in m.named_parameters():
+        if n in want:
+            worst = max(worst, float((p.grad - want[n]).abs().max()) / (float(want[n].abs().max()) + 1e-30))
+torch.cuda.synchronize()
+if rank == 0:
+    print("RESULT " + json.dumps({{"worst": worst, "launched": launched, "written": written, "buckets": len(pp.buckets)}}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_exchange_on_the_device(tmp_path):
+    """The N > 1 path with the real kernels: two ranks (sharing the box's one GPU; gloo carries the device buffers) run
+    different patches through PatchParallel -- direct weight-gradient writes on the side stream, hand-over of the small
+    gradients, hook-launched bucket exchanges issued from the side stream, division by the world size -- and every
+    gradient must equal the mean of the two single-rank gradients."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_ranks.py"
+    script.write_text(TWO_RANK_SCRIPT.format(root=root))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["worst"] <= 2e-5, res
+    assert min(res["launched"]) >= res["buckets"] - 2, res
+    assert min(res["written"]) >= 20, res
+
+
 def test_side_stream_weight_gradients_change_nothing():
     """PatchParallel(wgrad_stream=True): the direct-route weight-gradient kernels run on a second HIP stream while the
     main stream continues with the input-gradient chain.  Same kernels on the same operands, so the gradients must
