@@ -420,7 +420,7 @@ def gather_gemm(*args):
     d = L.GatherGemmDesc()
     flops = _gg_desc(d, *args)
     if args[0].dtype == torch.bfloat16:
-        with _timed("gather_gemm_bf16", flops):
+        with _timed("gather_gemm_bf16", flops, lambda: _gg_tag(d)):
             L.check(L.load().rehr_gather_gemm_bf16(C.byref(d), _stream()), "rehr_gather_gemm_bf16")
         return
     arr = (L.GatherGemmDesc * 1)(d)
@@ -441,7 +441,7 @@ def gather_gemm_multi(calls):
         needs.append(_gg_desc.need)
         sigs.append(_gg_desc.sig)
     if calls[0][0].dtype == torch.bfloat16:
-        with _timed("gather_gemm_bf16", flops):
+        with _timed("gather_gemm_bf16", flops, lambda: f"{len(calls)} parts of " + _gg_tag(arr[0])):
             L.check(L.load().rehr_gather_gemm_multi_bf16(arr, len(calls), _stream()), "rehr_gather_gemm_multi_bf16")
         return
     keep = _attach_ws(arr, len(calls), needs, sigs, calls[0][11])   # every part its own scratch: ONE launch runs them all
@@ -507,7 +507,8 @@ def wgrad(l, Ca, g, Cg, N, lattice, g_dims, s, b, taps, KH, KW, dst, dst_off, ds
             L.check(int(nbytes), "rehr_wgrad_bf16_workspace_bytes")
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=l.device)
         d.workspace, d.workspace_bytes = _ptr(ws), nbytes
-        with _timed("wgrad_bf16", flops):
+        with _timed("wgrad_bf16", flops, lambda: f"N{N} {Ca}x{Cg} lattice {tuple(lattice)} stride {tuple(s)} "
+                                             f"taps {taps[0][0]}x{taps[1][0]}x{taps[2][0]}"):
             L.check(lib.rehr_wgrad_bf16(C.byref(d), _stream()), "rehr_wgrad_bf16")
         return
     nbytes = lib.rehr_wgrad_workspace_bytes(C.byref(d))
