@@ -62,10 +62,18 @@ class PatchParallel:
         self._params_of_bucket = []
         self._view = {}
         off = 0
+        # The LAST bucket is the one exchange nothing hides (its gradients complete at the very end of backward), so the
+        # tail of the buffer -- the last `bucket_elems` elements -- is cut into buckets that halve in size down to 1/16 of
+        # a bucket: the exposed message is a few MiB instead of up to a whole bucket (FLAVR at cfg-2: 79 + 69 + 32 MiB
+        # became 79 + 56 + 21 + 14 + 5 + 4 + 2 MiB: layer3 / layer2 go out while layer1 and the stem are still being computed).
+        tail_from = total - bucket_elems
+        cap = bucket_elems
         for p in reversed(self.params):
             n = p.numel()
             self._view[id(p)] = p.grad = self.flat[off:off + n].view_as(p)
-            if not self.buckets or off - self.buckets[-1][0] >= bucket_elems:
+            if self.buckets and off >= tail_from and off - self.buckets[-1][0] >= cap // 2 and cap > bucket_elems // 16:
+                cap //= 2                                       # inside the tail: every new bucket half the previous cap
+            if not self.buckets or off - self.buckets[-1][0] >= cap:
                 self.buckets.append([off, off + n])
                 self._params_of_bucket.append([])
             self.buckets[-1][1] = off + n
