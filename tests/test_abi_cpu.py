@@ -41,3 +41,20 @@ def test_product_path_refuses_cpu_tensors():
     from rehrseg_amd import ops
     with pytest.raises(L.RehrsegHipError):
         ops.fused_conv3d(torch.randn(1, 32, 2, 4, 4), torch.randn(32, 32, 3, 3, 3), None, 1, 1)
+
+
+def test_flag_constants_of_the_binding_equal_the_header():
+    """Every REHR_GG_* / REHR_DBG_* bit the Python binding uses carries the value the header defines (a renumbered bit
+    would silently select another kernel or, for REHR_GG_WS_ONLY / _READY, skip or repeat a weight transform)."""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rehrseg_hip.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+REHR_(\w+)\s+(0x[0-9a-fA-F]+|\d+)\s", hdr)}
+    checked = 0
+    for name in dir(L):
+        if name.startswith(("GG_", "DBG_")) and isinstance(getattr(L, name), int):
+            assert name in defs, f"lib.{name} has no REHR_{name} in the header"
+            assert defs[name] == getattr(L, name), (name, defs[name], getattr(L, name))
+            checked += 1
+    assert checked >= 12
+    assert defs["GG_WS_READY"] != defs["GG_WS_ONLY"] and defs["GG_Y_F32"] == 1
