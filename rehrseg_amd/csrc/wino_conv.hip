@@ -555,6 +555,10 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
   BIG8_FENCE();                                                               \
   load_u(NEXT_T, NEXT_KK, 1, u1);
 
+#ifdef BIG8_STAMPS
+  long long b8_bar = 0;
+  const long long b8_t0 = __builtin_readcyclecounter();
+#endif
   for (int it = 0; it < items; ++it) {
     const int cur = (it & 1) * BUF, nxt = cur ^ BUF;
     advance(ni);
@@ -573,7 +577,13 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
     mfmas(0, VB, u0);
     __builtin_amdgcn_sched_barrier(0);
     load_u(ni, 0, 0, u0);
+#ifdef BIG8_STAMPS
+    const long long sa_ = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef BIG8_STAMPS
+    b8_bar += __builtin_readcyclecounter() - sa_;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     BIG8_PRIO(3);
     issue_reads(nxt, 0);
@@ -585,6 +595,11 @@ __global__ __launch_bounds__(512) void wino_conv_big8_kernel(const WinoParams p)
   }
 #undef BIG8_KGROUP
   BIG8_PRIO(0);
+#ifdef BIG8_STAMPS
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 777 && blockIdx.y == 0 && blockIdx.z == 0)
+    printf("big8 wave %d items %d: loop %lld cycles, barrier waits %lld\n", (int)(threadIdx.x >> 6), items,
+           (long long)(__builtin_readcyclecounter() - b8_t0), b8_bar);
+#endif
   __syncthreads();
 
   // ---- output transform: columns in registers, rows across the 4 row-waves of a tile group through LDS
